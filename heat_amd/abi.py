@@ -1,0 +1,228 @@
+"""ctypes view of the C ABI in include/heat_cf.h (lib/libheat_cf.so).
+
+Used by tests/, bench.py and the multi-GPU driver; the reference-compatible surface is heat_amd.cf_c.
+Loading fails loudly when the library has not been built — there is no fallback implementation.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libheat_cf.so")
+
+OK, EINVAL, EHIP, ENOMEM, EUNSUP = 0, -1, -2, -3, -4
+FLAG_SERIAL, FLAG_LAZY_SYNC, FLAG_SAMPLING_CALL = 0x1, 0x2, 0x4
+COHERENCE_DEFAULT, COHERENCE_PLAIN, COHERENCE_DEVICE = 0, 1, 2
+
+
+class Config(C.Structure):
+    """struct heat_cf_config (include/heat_cf.h) — replaces cf::modules::CFConfig (cf_config.hpp:12-35)."""
+    _fields_ = [("emb_dim", C.c_uint64), ("num_negs", C.c_uint64), ("num_users", C.c_uint64),
+                ("num_items", C.c_uint64), ("train_size", C.c_uint64), ("neg_sampler", C.c_uint64),
+                ("tile_size", C.c_uint64), ("refresh_interval", C.c_uint64), ("num_subepochs", C.c_uint64),
+                ("l2", C.c_float), ("clip_val", C.c_float), ("milestones", C.POINTER(C.c_uint64)),
+                ("n_milestones", C.c_uint64), ("l_r", C.c_float),
+                ("seed", C.c_uint64), ("sample_index_base", C.c_uint64), ("use_aggregator", C.c_uint32),
+                ("flags", C.c_uint32), ("coherence", C.c_uint32), ("device", C.c_int32),
+                ("num_streams", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class DeviceView(C.Structure):
+    _fields_ = [("user_w", C.c_void_p), ("item_w", C.c_void_p), ("user_g", C.c_void_p), ("item_g", C.c_void_p),
+                ("w0", C.c_void_p), ("clicks", C.c_void_p), ("data_rows", C.c_uint64), ("stream", C.c_void_p)]
+
+
+# every symbol include/heat_cf.h declares (tests/test_abi_symbols.py checks the header against this list)
+SYMBOLS = {
+    "heat_cf_abi_version": (C.c_int, []),
+    "heat_cf_last_error": (C.c_char_p, []),
+    "heat_cf_device_count": (C.c_int, []),
+    "heat_cf_engine_create": (C.c_int, [C.POINTER(Config), C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p,
+                                        C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "heat_cf_engine_create_device": (C.c_int, [C.POINTER(Config), C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
+                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                               C.POINTER(C.c_void_p)]),
+    "heat_cf_engine_destroy": (None, [C.c_void_p]),
+    "heat_cf_train_one_epoch": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
+    "heat_cf_begin_epoch": (C.c_int, [C.c_void_p]),
+    "heat_cf_train_range": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.POINTER(C.c_double)]),
+    "heat_cf_end_epoch": (C.c_int, [C.c_void_p]),
+    "heat_cf_sample_negatives": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]),
+    "heat_cf_evaluate0": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "heat_cf_topk": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "heat_cf_sync_to_host": (C.c_int, [C.c_void_p]),
+    "heat_cf_sync_from_host": (C.c_int, [C.c_void_p]),
+    "heat_cf_synchronize": (C.c_int, [C.c_void_p]),
+    "heat_cf_get_device_view": (C.c_int, [C.c_void_p, C.POINTER(DeviceView)]),
+    "heat_cf_epoch": (C.c_uint64, [C.c_void_p]),
+    "heat_cf_learning_rate": (C.c_float, [C.c_void_p]),
+    "heat_cf_set_learning_rate": (C.c_int, [C.c_void_p, C.c_float]),
+    "heat_cf_set_epoch": (C.c_int, [C.c_void_p, C.c_uint64]),
+    "heat_cf_zero_grad": (C.c_int, [C.c_void_p]),
+    "heat_cf_kernel_time": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int]),
+    "heat_cf_kernel_name": (C.c_char_p, [C.c_void_p]),
+}
+
+_lib = None
+
+
+def load():
+    """dlopen lib/libheat_cf.so and type every entry point.  Raises if the HIP library is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} is missing: build it with `python -m heat_amd.build` "
+                              "(hipcc --offload-arch=gfx950); heat_amd has no CPU fallback")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        if lib.heat_cf_abi_version() != 1:
+            raise ImportError("libheat_cf.so ABI version mismatch")
+        _lib = lib
+    return _lib
+
+
+class HeatError(RuntimeError):
+    pass
+
+
+def _check(rc):
+    if rc != OK:
+        msg = load().heat_cf_last_error().decode()
+        if rc == EINVAL:
+            raise ValueError(msg)
+        if rc == ENOMEM:
+            raise MemoryError(msg)
+        raise HeatError(f"[{rc}] {msg}")
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def make_config(*, emb_dim, num_negs, num_users, num_items, train_size, neg_sampler=0, tile_size=512,
+                refresh_interval=8192, num_subepochs=2, l2=1e-7, clip_val=1.0, milestones=(10,), l_r=0.01, seed=2022,
+                sample_index_base=0, use_aggregator=False, flags=0, coherence=COHERENCE_DEFAULT, device=-1,
+                num_streams=0):
+    ms = np.ascontiguousarray(np.asarray(list(milestones), dtype=np.uint64))
+    cfg = Config(emb_dim, num_negs, num_users, num_items, train_size, neg_sampler, tile_size, refresh_interval,
+                 num_subepochs, l2, clip_val, ms.ctypes.data_as(C.POINTER(C.c_uint64)), len(ms), l_r, seed,
+                 sample_index_base, int(use_aggregator), flags, coherence, device, num_streams, 0)
+    cfg._keepalive = ms
+    return cfg
+
+
+def _require(a, dtype, ndim, name):
+    if not isinstance(a, np.ndarray) or a.dtype != dtype or a.ndim != ndim or not a.flags.c_contiguous:
+        raise ValueError(f"{name} must be a C-contiguous {ndim}-D numpy array of {np.dtype(dtype).name}")
+
+
+class Engine:
+    """Host-mode engine: numpy buffers are borrowed and trained in place (like the reference's pybind layer)."""
+
+    def __init__(self, clicks, user_w, item_w, *, num_negs, his=None, masks=None, w0=None, **cfg_kwargs):
+        _require(clicks, np.uint64, 2, "clicks")
+        _require(user_w, np.float32, 2, "user_w")
+        _require(item_w, np.float32, 2, "item_w")
+        if clicks.shape[1] != 2 or user_w.shape[1] != item_w.shape[1]:
+            raise ValueError("clicks must be [n,2]; user_w and item_w must share emb_dim")
+        self._keep = (clicks, user_w, item_w, his, masks, w0)
+        self.num_negs = num_negs
+        self.data_rows = clicks.shape[0]
+        self.cfg = make_config(emb_dim=user_w.shape[1], num_negs=num_negs, num_users=user_w.shape[0],
+                               num_items=item_w.shape[0], train_size=clicks.shape[0], **cfg_kwargs)
+        self._h = C.c_void_p()
+        max_his = his.shape[1] if his is not None else 0
+        _check(load().heat_cf_engine_create(C.byref(self.cfg), _ptr(clicks), clicks.shape[0], _ptr(his), max_his,
+                                            _ptr(masks), _ptr(user_w), _ptr(item_w), _ptr(w0), C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            load().heat_cf_engine_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def train_one_epoch(self):
+        loss = C.c_float()
+        _check(load().heat_cf_train_one_epoch(self._h, C.byref(loss)))
+        return float(loss.value)
+
+    def begin_epoch(self):
+        _check(load().heat_cf_begin_epoch(self._h))
+
+    def end_epoch(self):
+        _check(load().heat_cf_end_epoch(self._h))
+
+    def train_range(self, begin, end, neg_ids=None, want_loss=True):
+        if neg_ids is not None:
+            neg_ids = np.ascontiguousarray(neg_ids, dtype=np.uint64)
+            if neg_ids.shape != (end - begin, self.num_negs):
+                raise ValueError("neg_ids must be [end-begin, num_negs]")
+        loss = C.c_double()
+        _check(load().heat_cf_train_range(self._h, begin, end, _ptr(neg_ids), C.byref(loss) if want_loss else None))
+        return float(loss.value) if want_loss else None
+
+    def sample_negatives(self, begin, end):
+        out = np.empty((end - begin, self.num_negs), dtype=np.uint64)
+        _check(load().heat_cf_sample_negatives(self._h, begin, end, _ptr(out)))
+        return out
+
+    def evaluate0(self):
+        sim = np.empty((self.cfg.num_users, self.cfg.num_items), dtype=np.float32)
+        _check(load().heat_cf_evaluate0(self._h, _ptr(sim)))
+        return sim
+
+    def topk(self, k, u_begin=0, u_end=None, mask_indptr=None, mask_items=None):
+        u_end = self.cfg.num_users if u_end is None else u_end
+        out = np.empty((u_end - u_begin, k), dtype=np.uint32)
+        if mask_indptr is not None:
+            mask_indptr = np.ascontiguousarray(mask_indptr, dtype=np.uint64)
+            mask_items = np.ascontiguousarray(mask_items, dtype=np.uint32)
+        _check(load().heat_cf_topk(self._h, u_begin, u_end, k, _ptr(mask_indptr), _ptr(mask_items), _ptr(out)))
+        return out
+
+    def sync_to_host(self):
+        _check(load().heat_cf_sync_to_host(self._h))
+
+    def sync_from_host(self):
+        _check(load().heat_cf_sync_from_host(self._h))
+
+    def synchronize(self):
+        _check(load().heat_cf_synchronize(self._h))
+
+    def zero_grad(self):
+        _check(load().heat_cf_zero_grad(self._h))
+
+    def device_view(self):
+        v = DeviceView()
+        _check(load().heat_cf_get_device_view(self._h, C.byref(v)))
+        return v
+
+    @property
+    def epoch(self):
+        return int(load().heat_cf_epoch(self._h))
+
+    @epoch.setter
+    def epoch(self, v):
+        _check(load().heat_cf_set_epoch(self._h, v))
+
+    @property
+    def l_r(self):
+        return float(load().heat_cf_learning_rate(self._h))
+
+    @l_r.setter
+    def l_r(self, v):
+        _check(load().heat_cf_set_learning_rate(self._h, v))
+
+    def kernel_time(self, reset=False):
+        ms, n = C.c_double(), C.c_uint64()
+        _check(load().heat_cf_kernel_time(self._h, C.byref(ms), C.byref(n), int(reset)))
+        return float(ms.value), int(n.value)
+
+    @property
+    def kernel_name(self):
+        return load().heat_cf_kernel_name(self._h).decode()

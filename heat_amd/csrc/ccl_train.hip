@@ -1,0 +1,387 @@
+// ccl_train.hip — the fused per-interaction SimpleX/CCL step as hand-written gfx950 HIP.
+//
+// What it replaces (paths relative to /root/reference/cf_cpu/src):
+//   models/matrix_factorization.cpp:15-181   forward_backward (gather, 3+2N dots, cosine, softmax-CE, grads)
+//   optimizers/sgd.cpp:14-26, optimizer.cpp:17-22   clip + SGD on persistent gradient rows
+//   negative_samplers/uniform_random_negative_sampler.cpp:17-36   uniform negatives (here: Philox on the GPU)
+//   train/engine.cpp:327-340   the per-thread sequential walk over a chunk of interactions
+//   memory/array.hpp:46-55     row gather / scatter (here: 16-byte-per-lane buffer loads/stores)
+//
+// Mapping to CDNA4
+//   * one 64-lane wavefront = one sequential interaction stream (the analogue of one OpenMP thread walking a
+//     `schedule(dynamic,512)` chunk): all interactions of a stream are processed in stored order, so a user's
+//     run is updated sequentially and the user row lives in registers while the user does not change;
+//   * an embedding row is read by LPR = emb_dim/4 (rounded up to 8/16/32/64) consecutive lanes, 16 B per lane
+//     (one `buffer_load_dwordx4` fetches R = 64/LPR whole rows); row-wise dot products are 4 DPP adds inside
+//     the 16-lane DPP row (+ ds_bpermute steps for 128/256-wide rows);
+//   * the N negatives sit in NG = ceil(N/R) register groups; per-negative scalars (norms, cosines, softmax
+//     weights) are computed once per row group, the softmax runs across groups and rows with two cross-row
+//     shuffles;
+//   * stores are Hogwild (plain overwrites of W and G rows, no atomics), exactly the reference's semantics;
+//     with AUX = sc1 the row traffic is device-coherent across the 8 XCD L2s;
+//   * negatives come from Philox4x32-10 keyed by (seed, epoch) with the interaction index as counter: no host
+//     round trip, no sampler state in memory, schedule-independent.
+#include "ccl_device.hpp"
+#include "ccl_train.hpp"
+
+namespace heatcf
+{
+
+template <int LPR, int NG, int AUX>
+__global__ __launch_bounds__(64) void ccl_train_kernel(TrainArgs a)
+{
+    constexpr int R = 64 / LPR;          // rows fetched by one wave instruction
+    constexpr int NCAP = NG * R;         // negative slots held in registers
+    constexpr int NIDV = (NCAP + 63) / 64;
+    const int lane = (int)threadIdx.x;
+    const int sub = lane & (LPR - 1);    // 16-byte column of the row
+    const int rr = lane / LPR;           // which of the R rows of a group this lane serves
+    const uint32_t col_off = (uint32_t)sub * 16u;
+    const bool col_ok = col_off < a.row_bytes;
+    const uint32_t N = a.num_negs;
+    const float lr = a.lr, clip = a.clip;
+    const float eps = 1e-8f;             // matrix_factorization.cpp:53
+    const float score_mul = (float)(1.0 / 0.07); // :101-103 (double converted to the array's scalar type)
+
+    const __amdgpu_buffer_rsrc_t item_w = make_rsrc(a.item_w, a.item_bytes);
+    const __amdgpu_buffer_rsrc_t item_g = make_rsrc(a.item_g, a.item_bytes);
+
+    const uint64_t first = a.begin + (uint64_t)blockIdx.x * a.per_block;
+    uint64_t last = first + a.per_block;
+    if (last > a.end) last = a.end;
+
+    uint32_t cur_user = 0xFFFFFFFFu;
+    f32x4 u4 = {0, 0, 0, 0}, gu4 = {0, 0, 0, 0};
+    uint32_t nid[NIDV];
+#pragma unroll
+    for (int v = 0; v < NIDV; ++v) nid[v] = 0u; // engine.cpp:298: neg_ids zero-initialised per worker
+    double loss_acc = 0.0;
+
+    for (uint64_t base = first; base < last; base += 64)
+    {
+        // one coalesced load brings the (user,item) pairs of the next 64 interactions (datasets/click_dataset.cpp:17-22)
+        uint2 pair = make_uint2(0u, 0u);
+        if (base + (uint64_t)lane < last) pair = a.clicks[base + (uint64_t)lane];
+        const int cnt = (last - base) < 64 ? (int)(last - base) : 64;
+
+        for (int j = 0; j < cnt; ++j)
+        {
+            const uint32_t user = (uint32_t)__builtin_amdgcn_readlane((int)pair.x, j);
+            const uint32_t pos = (uint32_t)__builtin_amdgcn_readlane((int)pair.y, j);
+            const uint64_t idx = base + (uint64_t)j;
+
+            // ---- negatives: lane k (register v) owns slot v*64+k ---------------------------------------
+#pragma unroll
+            for (int v = 0; v < NIDV; ++v)
+            {
+                const uint32_t slot = (uint32_t)(v * 64 + lane);
+                uint32_t id;
+                if (a.ext_negs != nullptr)
+                {
+                    id = slot < N ? a.ext_negs[(idx - a.ext_base) * N + slot] : 0u;
+                }
+                else
+                {
+                    id = uniform_item(philox_draw64(slot, a.sample_base + idx, a.key), a.num_items);
+                    // ignore_pos_sampling (uniform_random_negative_sampler.cpp:26-36): a draw equal to the
+                    // positive leaves the slot unchanged (previous interaction's id, initially 0)
+                    if (!a.sampling_call && id == pos) id = nid[v];
+                }
+                nid[v] = id;
+                if (a.neg_out != nullptr && slot < N) a.neg_out[(idx - a.neg_out_base) * N + slot] = id;
+            }
+
+            // ---- user row: registers while the user does not change (write back on change) -----------------
+            if (user != cur_user)
+            {
+                if (cur_user != 0xFFFFFFFFu && rr == 0 && col_ok)
+                {
+                    const size_t o = (size_t)cur_user * a.row_bytes;
+                    buf_store<AUX>(make_rsrc((const char*)a.user_w + o, a.row_bytes), col_off, u4);
+                    buf_store<AUX>(make_rsrc((const char*)a.user_g + o, a.row_bytes), col_off, gu4);
+                }
+                cur_user = user;
+                const size_t o = (size_t)user * a.row_bytes;
+                const uint32_t uo = col_ok ? col_off : OOB_OFF;
+                u4 = buf_load<AUX>(make_rsrc((const char*)a.user_w + o, a.row_bytes), uo);
+                gu4 = buf_load<AUX>(make_rsrc((const char*)a.user_g + o, a.row_bytes), uo);
+            }
+
+            // ---- gather: positive row (replicated in every row group) + N negative rows, W and G -----------
+            const uint32_t poff = col_ok ? pos * a.row_bytes + col_off : OOB_OFF;
+            f32x4 p4 = buf_load<AUX>(item_w, poff);
+            f32x4 gp4 = buf_load<AUX>(item_g, poff);
+
+            f32x4 n4[NG], gn4[NG];
+            uint32_t noff[NG];
+            bool valid[NG];
+#pragma unroll
+            for (int g = 0; g < NG; ++g)
+            {
+                const int k = g * R + rr;                    // slot of this lane's row in group g
+                const uint32_t id = lane_get(nid[(g * R) / 64], k & 63);
+                valid[g] = (uint32_t)k < N;
+                // a negative that equals the positive is not written: the positive's write-back comes last
+                // in the reference (matrix_factorization.cpp:171-174) and overwrites it
+                noff[g] = (valid[g] && col_ok) ? id * a.row_bytes + col_off : OOB_OFF;
+                n4[g] = buf_load<AUX>(item_w, noff[g]);
+                gn4[g] = buf_load<AUX>(item_g, noff[g]);
+                if (id == pos) noff[g] = OOB_OFF;
+            }
+
+            // ---- duplicate negatives inside one interaction (rare): multiplicity per slot ------------------
+            // Reference semantics (matrix_factorization.cpp:127-150): slot k re-reads G fresh, so c copies of one
+            // row apply G <- clip(G + g) c times; every copy writes W_stale - lr*G, last writer wins.  All copies
+            // compute the identical c-fold result here, so whichever store lands last is the reference's value.
+            uint32_t cmul[NG];
+            uint32_t cmax = 1u;
+            {
+                uint32_t eq[NIDV];
+#pragma unroll
+                for (int v = 0; v < NIDV; ++v) eq[v] = 0u;
+                for (uint32_t s = 0; s < N; ++s)
+                {
+                    uint32_t sid = 0u;
+#pragma unroll
+                    for (int v = 0; v < NIDV; ++v)
+                        if ((int)(s >> 6) == v) sid = (uint32_t)__builtin_amdgcn_readlane((int)nid[v], (int)(s & 63u));
+#pragma unroll
+                    for (int v = 0; v < NIDV; ++v) eq[v] += (nid[v] == sid && (uint32_t)(v * 64 + lane) < N) ? 1u : 0u;
+                }
+                bool any_dup = false;
+#pragma unroll
+                for (int v = 0; v < NIDV; ++v) any_dup = any_dup || (eq[v] > 1u);
+                if (__builtin_amdgcn_ballot_w64(any_dup) != 0ull)
+                {
+#pragma unroll
+                    for (int g = 0; g < NG; ++g)
+                    {
+                        cmul[g] = valid[g] ? lane_get(eq[(g * R) / 64], (g * R + rr) & 63) : 1u;
+                        cmax = cmul[g] > cmax ? cmul[g] : cmax;
+                    }
+                    // wave-uniform upper bound
+#pragma unroll
+                    for (int m = 1; m < 64; m <<= 1)
+                    {
+                        const uint32_t o = lane_get(cmax, lane ^ m);
+                        cmax = o > cmax ? o : cmax;
+                    }
+                }
+                else
+                {
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) cmul[g] = 1u;
+                }
+            }
+
+            // ---- forward: dots, cosines, softmax cross-entropy (matrix_factorization.cpp:43-109) -----------
+            const float uu = row_sum<LPR>(dot4(u4, u4));
+            const float pp = row_sum<LPR>(dot4(p4, p4));
+            const float up = row_sum<LPR>(dot4(u4, p4));
+            const float unorm = sqrtf(fmaxf(uu, eps));
+            const float pnorm = sqrtf(fmaxf(pp, eps));
+            const float unorm3 = unorm * unorm * unorm;
+            const float pnorm3 = pnorm * pnorm * pnorm;
+            const float r_u3_p = 1.0f / (unorm3 * pnorm);
+            const float r_u_p3 = 1.0f / (unorm * pnorm3);
+            const float upcos = up / (unorm * pnorm);
+
+            float un[NG], nn[NG], nnorm[NG], score[NG];
+            float mx = -INFINITY;
+#pragma unroll
+            for (int g = 0; g < NG; ++g)
+            {
+                un[g] = row_sum<LPR>(dot4(u4, n4[g]));
+                nn[g] = row_sum<LPR>(dot4(n4[g], n4[g]));
+                nnorm[g] = sqrtf(nn[g] < eps ? eps : nn[g]);
+                const float c = un[g] / (unorm * nnorm[g]);
+                score[g] = valid[g] ? (c - upcos) * score_mul : -INFINITY;
+                mx = fmaxf(mx, score[g]);
+            }
+            mx = cross_max<LPR>(mx);
+            float es[NG];
+            float ssum = 0.0f;
+#pragma unroll
+            for (int g = 0; g < NG; ++g)
+            {
+                es[g] = valid[g] ? expf(score[g] - mx) : 0.0f;
+                ssum += es[g];
+            }
+            ssum = cross_sum<LPR>(ssum);
+            // :106 adds exp(-max) computed in double; fp32 expf differs by <= 1 ulp of the sum
+            const float Z = ssum + expf(-mx);
+            const float loss = mx + logf(Z);
+            loss_acc += (double)loss;
+
+            // ---- backward + clipped SGD + scatter (matrix_factorization.cpp:118-174, sgd.cpp:14-26) ----------
+            // u_p_cos_u_grad, u_p_cos_p_grad (:62-63)
+            const f32x4 upu = (uu * p4 - up * u4) * r_u3_p;
+            const f32x4 upp = -(pp * u4 - up * p4) * r_u_p3;
+            f32x4 gu_acc = {0, 0, 0, 0};
+            float slg = 0.0f;
+#pragma unroll
+            for (int g = 0; g < NG; ++g)
+            {
+                const float lg = (es[g] / Z) * score_mul;                       // :109
+                const float nnorm3 = nnorm[g] * nnorm[g] * nnorm[g];
+                const float r_u3_n = 1.0f / (unorm3 * nnorm[g]);                // :136
+                const float r_u_n3 = 1.0f / (unorm * nnorm3);                   // :137
+                const f32x4 unu = (uu * n4[g] - un[g] * u4) * r_u3_n;           // :138
+                const f32x4 unn = (nn[g] * u4 - un[g] * n4[g]) * r_u_n3;        // :139 (raw nn, not eps-clamped)
+                gu_acc += lg * (unu - upu);                                     // :141
+                slg += lg;                                                      // :142 (pos grad += lg * upp)
+                const f32x4 t = lg * unn;
+                f32x4 gn = clip4(gn4[g] + t, clip);                             // :143,147 + sgd.cpp:22
+                for (uint32_t c = 1; c < cmax; ++c)
+                {
+                    const f32x4 g2 = clip4(gn + t, clip);
+                    if (c < cmul[g]) gn = g2;
+                }
+                const f32x4 nw = n4[g] - lr * gn;                               // sgd.cpp:23
+                buf_store<AUX>(item_w, noff[g], nw);                            // :148
+                buf_store<AUX>(item_g, noff[g], gn);                            // :149
+            }
+            gu_acc.x = cross_sum<LPR>(gu_acc.x);
+            gu_acc.y = cross_sum<LPR>(gu_acc.y);
+            gu_acc.z = cross_sum<LPR>(gu_acc.z);
+            gu_acc.w = cross_sum<LPR>(gu_acc.w);
+            slg = cross_sum<LPR>(slg);
+
+            gu4 = clip4(gu4 + gu_acc, clip);                                    // :166
+            u4 = u4 - lr * gu4;
+            gp4 = clip4(gp4 + slg * upp, clip);                                 // :169
+            p4 = p4 - lr * gp4;
+            const uint32_t pst = (rr == 0 && col_ok) ? pos * a.row_bytes + col_off : OOB_OFF;
+            buf_store<AUX>(item_w, pst, p4);                                    // :173
+            buf_store<AUX>(item_g, pst, gp4);                                   // :174
+        }
+    }
+
+    if (cur_user != 0xFFFFFFFFu && rr == 0 && col_ok)
+    {
+        const size_t o = (size_t)cur_user * a.row_bytes;
+        buf_store<AUX>(make_rsrc((const char*)a.user_w + o, a.row_bytes), col_off, u4);   // :171
+        buf_store<AUX>(make_rsrc((const char*)a.user_g + o, a.row_bytes), col_off, gu4);  // :172
+    }
+    if (lane == 0) a.loss_part[blockIdx.x] = loss_acc;
+}
+
+// Deterministic fixed-order reduction of the per-stream loss partials (fp64), accumulated into *out.
+__global__ __launch_bounds__(256) void loss_reduce_kernel(const double* part, uint32_t n, double* out)
+{
+    __shared__ double sh[256];
+    double s = 0.0;
+    for (uint32_t i = threadIdx.x; i < n; i += 256) s += part[i];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1)
+    {
+        if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *out += sh[0];
+}
+
+// u64 (user,item) pairs -> packed u32 pairs + range check (max ids written with atomicMax)
+__global__ void pack_clicks_kernel(const uint64_t* in, uint2* out, uint64_t n, uint32_t* max_user, uint32_t* max_item,
+                                   uint32_t* overflow)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t u = in[2 * i], it = in[2 * i + 1];
+    if ((u >> 32) || (it >> 32)) atomicOr(overflow, 1u);
+    out[i] = make_uint2((uint32_t)u, (uint32_t)it);
+    atomicMax(max_user, (uint32_t)u);
+    atomicMax(max_item, (uint32_t)it);
+}
+
+// Sampler-only kernel: the ids the training kernel draws for interactions [begin,end) (tests, oracle feeding).
+// One wave walks the range sequentially so that the ignore_pos "slot keeps previous id" state is reproduced for the
+// stream layout given by per_block.
+__global__ __launch_bounds__(64) void sample_negs_kernel(TrainArgs a, uint64_t out_base, uint64_t* out)
+{
+    const int lane = (int)threadIdx.x;
+    const uint32_t N = a.num_negs;
+    const uint64_t first = a.begin + (uint64_t)blockIdx.x * a.per_block;
+    uint64_t last = first + a.per_block;
+    if (last > a.end) last = a.end;
+    const int nidv = (int)((N + 63u) / 64u);
+    uint32_t prev[4] = {0u, 0u, 0u, 0u};
+    for (uint64_t idx = first; idx < last; ++idx)
+    {
+        const uint32_t pos = a.clicks[idx].y;
+        for (int v = 0; v < nidv && v < 4; ++v)
+        {
+            const uint32_t slot = (uint32_t)(v * 64 + lane);
+            uint32_t id = uniform_item(philox_draw64(slot, a.sample_base + idx, a.key), a.num_items);
+            if (!a.sampling_call && id == pos) id = prev[v];
+            prev[v] = id;
+            if (slot < N) out[(idx - out_base) * N + slot] = (uint64_t)id;
+        }
+    }
+}
+
+// ---- dispatch -------------------------------------------------------------------------------------------------
+template <int LPR, int NG>
+static hipError_t launch_variant(const TrainArgs& a, uint32_t grid, int aux, hipStream_t s)
+{
+    if (aux == AUX_PLAIN)
+        hipLaunchKernelGGL((ccl_train_kernel<LPR, NG, AUX_PLAIN>), dim3(grid), dim3(64), 0, s, a);
+    else
+        hipLaunchKernelGGL((ccl_train_kernel<LPR, NG, AUX_SC1>), dim3(grid), dim3(64), 0, s, a);
+    return hipGetLastError();
+}
+
+#define HEATCF_VARIANTS(X) \
+    X(8, 1) X(8, 2) X(8, 4) X(8, 8) \
+    X(16, 2) X(16, 4) X(16, 8) X(16, 16) X(16, 25) \
+    X(32, 4) X(32, 8) X(32, 16) X(32, 32) \
+    X(64, 8) X(64, 16) X(64, 32)
+
+bool pick_variant(uint32_t emb_dim, uint32_t num_negs, int* lpr_out, int* ng_out)
+{
+    if (emb_dim == 0 || emb_dim % 4 != 0 || emb_dim > 256 || num_negs == 0) return false;
+    const uint32_t need = emb_dim / 4;
+    int lpr = 8;
+    while ((uint32_t)lpr < need) lpr <<= 1;
+    const int R = 64 / lpr;
+    const int need_ng = (int)((num_negs + R - 1) / R);
+    int best = 0;
+#define X(L, G) if (L == lpr && G >= need_ng && (best == 0 || G < best)) best = G;
+    HEATCF_VARIANTS(X)
+#undef X
+    if (best == 0) return false;
+    *lpr_out = lpr;
+    *ng_out = best;
+    return true;
+}
+
+hipError_t launch_train(const TrainArgs& a, int lpr, int ng, uint32_t grid, int aux, hipStream_t s)
+{
+#define X(L, G) if (lpr == L && ng == G) return launch_variant<L, G>(a, grid, aux, s);
+    HEATCF_VARIANTS(X)
+#undef X
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_loss_reduce(const double* part, uint32_t n, double* out, hipStream_t s)
+{
+    hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, s, part, n, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_pack_clicks(const uint64_t* in, uint2* out, uint64_t n, uint32_t* stats, hipStream_t s)
+{
+    if (n == 0) return hipSuccess;
+    const uint32_t blocks = (uint32_t)((n + 255) / 256);
+    hipLaunchKernelGGL(pack_clicks_kernel, dim3(blocks), dim3(256), 0, s, in, out, n, stats, stats + 1, stats + 2);
+    return hipGetLastError();
+}
+
+hipError_t launch_sample_negs(const TrainArgs& a, uint32_t grid, uint64_t out_base, uint64_t* out, hipStream_t s)
+{
+    hipLaunchKernelGGL(sample_negs_kernel, dim3(grid), dim3(64), 0, s, a, out_base, out);
+    return hipGetLastError();
+}
+
+} // namespace heatcf

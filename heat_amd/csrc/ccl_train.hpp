@@ -1,0 +1,41 @@
+// ccl_train.hpp — launch interface between the host engine (engine.cpp) and the gfx950 kernels (ccl_train.hip).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace heatcf
+{
+
+struct TrainArgs
+{
+    const uint2* clicks;     // [data_rows] packed {user, item} (u32)
+    float*       user_w;     // [num_users, emb_dim]
+    float*       user_g;
+    float*       item_w;     // [num_items, emb_dim]
+    float*       item_g;
+    uint64_t     begin, end; // interaction range of this launch
+    uint64_t     per_block;  // consecutive interactions walked by one wave (multiple of 64)
+    uint32_t     num_items, num_negs, emb_dim, row_bytes;
+    uint32_t     item_bytes; // num_items * row_bytes (< 4 GiB: 32-bit buffer offsets)
+    uint32_t     sampling_call;
+    float        lr, clip;
+    uint64_t     key;         // Philox key for this epoch
+    uint64_t     sample_base; // added to the interaction index in the Philox counter
+    const uint32_t* ext_negs; // optional caller-fed negatives [., num_negs], row (idx - ext_base)
+    uint64_t     ext_base;
+    uint32_t*    neg_out;     // optional record of the negatives used, row (idx - neg_out_base)
+    uint64_t     neg_out_base;
+    double*      loss_part;   // [grid] per-stream loss sums
+};
+
+// per-epoch sampler key: (seed, epoch) -> 64-bit Philox key (= the `seed` argument of hiprand_init)
+inline uint64_t epoch_key(uint64_t seed, uint64_t epoch) { return seed + 0x9E3779B97F4A7C15ull * (epoch + 1ull); }
+
+bool       pick_variant(uint32_t emb_dim, uint32_t num_negs, int* lpr, int* ng);
+hipError_t launch_train(const TrainArgs& a, int lpr, int ng, uint32_t grid, int aux, hipStream_t s);
+hipError_t launch_loss_reduce(const double* part, uint32_t n, double* out, hipStream_t s);
+hipError_t launch_pack_clicks(const uint64_t* in, uint2* out, uint64_t n, uint32_t* stats, hipStream_t s);
+hipError_t launch_sample_negs(const TrainArgs& a, uint32_t grid, uint64_t out_base, uint64_t* out, hipStream_t s);
+
+} // namespace heatcf

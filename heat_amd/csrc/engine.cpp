@@ -1,0 +1,708 @@
+// engine.cpp — host side of the C ABI declared in include/heat_cf.h.
+//
+// Owns the device-resident training state (packed interaction list, W/G tables), drives the gfx950 kernels of
+// ccl_train.hip on one HIP stream and implements the reference's epoch protocol
+// (train/engine.cpp:156-160 LR schedule, :294-342 pass over the interactions, :345-347 zero_grad, :378-385 mean loss).
+// There is no CPU compute path in this file: if HIP is unusable every entry point reports HEAT_CF_EHIP.
+#include "../../include/heat_cf.h"
+#include "ccl_train.hpp"
+#include "eval_kernels.hpp"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+using namespace heatcf;
+
+namespace
+{
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string& msg)
+{
+    g_last_error = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                           \
+    do                                                                                                          \
+    {                                                                                                           \
+        hipError_t _e = (expr);                                                                                 \
+        if (_e != hipSuccess)                                                                                   \
+            return fail(_e == hipErrorOutOfMemory ? HEAT_CF_ENOMEM : HEAT_CF_EHIP,                              \
+                        std::string(#expr) + ": " + hipGetErrorString(_e));                                     \
+    } while (0)
+
+struct EventPair
+{
+    hipEvent_t a, b;
+};
+} // namespace
+
+struct heat_cf_engine
+{
+    heat_cf_config        cfg{};
+    std::vector<uint64_t> milestones;
+    int                   device = 0;
+    hipStream_t           stream = nullptr;
+    bool                  own_stream = false;
+    bool                  host_mode = false;
+    // borrowed host buffers (host mode)
+    float* h_user_w = nullptr;
+    float* h_item_w = nullptr;
+    float* h_w0 = nullptr;
+    // device state
+    uint2*   d_clicks = nullptr;
+    float*   d_user_w = nullptr;
+    float*   d_item_w = nullptr;
+    float*   d_user_g = nullptr;
+    float*   d_item_g = nullptr;
+    float*   d_w0 = nullptr;
+    bool     own_tables = false;
+    uint64_t data_rows = 0;
+    // scratch
+    double*   d_loss_part = nullptr;
+    uint32_t  loss_cap = 0;
+    double*   d_sums = nullptr; // [0] epoch sum, [1] last range sum
+    uint32_t* d_ext_negs = nullptr;
+    size_t    ext_cap = 0;
+    uint32_t* d_stats = nullptr;
+    // scalar state
+    float    lr = 0.f;
+    uint64_t epoch = 0;
+    // kernel choice
+    int      lpr = 0, ng = 0, aux = 0;
+    uint32_t cu_count = 256;
+    char     kname[96] = {0};
+    // timing
+    std::vector<EventPair> ev_free, ev_pending;
+    double   kernel_ms = 0.0;
+    uint64_t launches = 0;
+};
+
+namespace
+{
+size_t user_bytes(const heat_cf_engine* e) { return (size_t)e->cfg.num_users * e->cfg.emb_dim * sizeof(float); }
+size_t item_bytes(const heat_cf_engine* e) { return (size_t)e->cfg.num_items * e->cfg.emb_dim * sizeof(float); }
+
+int validate_cfg(const heat_cf_config* cfg, uint64_t data_rows, int* lpr, int* ng)
+{
+    if (!cfg) return fail(HEAT_CF_EINVAL, "cfg is NULL");
+    if (cfg->num_users == 0 || cfg->num_items == 0) return fail(HEAT_CF_EINVAL, "num_users and num_items must be > 0");
+    if (cfg->emb_dim == 0 || cfg->emb_dim % 4 != 0 || cfg->emb_dim > 256)
+        return fail(HEAT_CF_EUNSUP, "emb_dim must be a multiple of 4 in [4,256] (16-byte row segments per lane)");
+    if (cfg->num_negs == 0) return fail(HEAT_CF_EINVAL, "num_negs must be > 0");
+    if (cfg->num_users >= 0xFFFFFFFFull || cfg->num_items >= 0xFFFFFFFFull)
+        return fail(HEAT_CF_EUNSUP, "ids must fit 32 bits on the device");
+    if ((uint64_t)cfg->num_items * cfg->emb_dim * 4ull >= (1ull << 32))
+        return fail(HEAT_CF_EUNSUP, "item table must be < 4 GiB (32-bit buffer offsets)");
+    if (cfg->n_milestones == 0 || cfg->milestones == nullptr)
+        return fail(HEAT_CF_EINVAL, "milestones must hold at least one epoch (engine.cpp:159 reads milestones[0])");
+    if (cfg->n_milestones == 1 && cfg->milestones[0] == 0)
+        return fail(HEAT_CF_EINVAL, "milestones[0] must be > 0 (optimizer.cpp:26 computes epoch % step_size)");
+    if (cfg->use_aggregator) return fail(HEAT_CF_EUNSUP, "behaviour aggregation (ACCL) is not built yet");
+    if (cfg->neg_sampler != 0 && cfg->neg_sampler != 1) return fail(HEAT_CF_EINVAL, "neg_sampler must be 0 or 1");
+    if (!pick_variant((uint32_t)cfg->emb_dim, (uint32_t)cfg->num_negs, lpr, ng))
+        return fail(HEAT_CF_EUNSUP, "no compiled kernel variant for this (emb_dim, num_negs)");
+    if (data_rows >= (1ull << 40)) return fail(HEAT_CF_EINVAL, "data_rows too large");
+    return HEAT_CF_OK;
+}
+
+int common_init(heat_cf_engine* e, const heat_cf_config* cfg, uint64_t data_rows, void* stream)
+{
+    e->cfg = *cfg;
+    e->milestones.assign(cfg->milestones, cfg->milestones + cfg->n_milestones);
+    e->cfg.milestones = e->milestones.data();
+    e->data_rows = data_rows;
+    e->lr = cfg->l_r; // optimizers/optimizer.cpp:13
+    e->epoch = 0;     // train/engine.cpp:19
+    int ndev = 0;
+    hipError_t err = hipGetDeviceCount(&ndev);
+    if (err != hipSuccess || ndev <= 0)
+        return fail(HEAT_CF_EHIP, "no usable HIP device (the engine has no CPU fallback)");
+    if (cfg->device >= 0)
+    {
+        if (cfg->device >= ndev) return fail(HEAT_CF_EINVAL, "device ordinal out of range");
+        HIP_TRY(hipSetDevice(cfg->device));
+        e->device = cfg->device;
+    }
+    else
+    {
+        HIP_TRY(hipGetDevice(&e->device));
+    }
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, e->device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(HEAT_CF_EHIP, std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950 only");
+    e->cu_count = (uint32_t)prop.multiProcessorCount;
+    if (stream)
+    {
+        e->stream = (hipStream_t)stream;
+        e->own_stream = false;
+    }
+    else
+    {
+        HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+        e->own_stream = true;
+    }
+    const uint32_t coh = cfg->coherence == HEAT_CF_COHERENCE_DEFAULT ? HEAT_CF_COHERENCE_DEVICE : cfg->coherence;
+    if (coh != HEAT_CF_COHERENCE_PLAIN && coh != HEAT_CF_COHERENCE_DEVICE) return fail(HEAT_CF_EINVAL, "bad coherence");
+    e->aux = coh == HEAT_CF_COHERENCE_DEVICE ? 16 : 0;
+    std::snprintf(e->kname, sizeof(e->kname), "ccl_train_kernel<%d,%d,%d>", e->lpr, e->ng, e->aux);
+    HIP_TRY(hipMalloc(&e->d_sums, 2 * sizeof(double)));
+    HIP_TRY(hipMemsetAsync(e->d_sums, 0, 2 * sizeof(double), e->stream));
+    HIP_TRY(hipMalloc(&e->d_stats, 4 * sizeof(uint32_t)));
+    return HEAT_CF_OK;
+}
+
+int ensure_loss_part(heat_cf_engine* e, uint32_t grid)
+{
+    if (grid <= e->loss_cap) return HEAT_CF_OK;
+    if (e->d_loss_part)
+    {
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        HIP_TRY(hipFree(e->d_loss_part));
+        e->d_loss_part = nullptr;
+    }
+    HIP_TRY(hipMalloc(&e->d_loss_part, (size_t)grid * sizeof(double)));
+    e->loss_cap = grid;
+    return HEAT_CF_OK;
+}
+
+int get_events(heat_cf_engine* e, EventPair* p)
+{
+    if (e->ev_pending.size() >= 1024)
+    {
+        // bound the pool: fold the oldest timings into the accumulator
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        for (auto& q : e->ev_pending)
+        {
+            float ms = 0.f;
+            HIP_TRY(hipEventElapsedTime(&ms, q.a, q.b));
+            e->kernel_ms += ms;
+            e->ev_free.push_back(q);
+        }
+        e->ev_pending.clear();
+    }
+    if (!e->ev_free.empty())
+    {
+        *p = e->ev_free.back();
+        e->ev_free.pop_back();
+        return HEAT_CF_OK;
+    }
+    HIP_TRY(hipEventCreate(&p->a));
+    HIP_TRY(hipEventCreate(&p->b));
+    return HEAT_CF_OK;
+}
+
+// grid geometry: `streams` sequential walkers, each over a contiguous run of interactions (multiple of 64)
+void geometry(const heat_cf_engine* e, uint64_t n, uint64_t* per_block, uint32_t* grid)
+{
+    if (e->cfg.flags & HEAT_CF_FLAG_SERIAL)
+    {
+        *per_block = ((n + 63) / 64) * 64;
+        *grid = 1;
+        return;
+    }
+    uint64_t streams = e->cfg.num_streams ? e->cfg.num_streams : (uint64_t)e->cu_count * 32ull;
+    uint64_t pb = (n + streams - 1) / streams;
+    pb = ((pb + 63) / 64) * 64;
+    if (pb == 0) pb = 64;
+    *per_block = pb;
+    *grid = (uint32_t)((n + pb - 1) / pb);
+}
+
+TrainArgs make_args(const heat_cf_engine* e, uint64_t begin, uint64_t end)
+{
+    TrainArgs a{};
+    a.clicks = e->d_clicks;
+    a.user_w = e->d_user_w;
+    a.user_g = e->d_user_g;
+    a.item_w = e->d_item_w;
+    a.item_g = e->d_item_g;
+    a.begin = begin;
+    a.end = end;
+    a.num_items = (uint32_t)e->cfg.num_items;
+    a.num_negs = (uint32_t)e->cfg.num_negs;
+    a.emb_dim = (uint32_t)e->cfg.emb_dim;
+    a.row_bytes = (uint32_t)e->cfg.emb_dim * 4u;
+    a.item_bytes = (uint32_t)(e->cfg.num_items * e->cfg.emb_dim * 4ull);
+    a.sampling_call = (e->cfg.flags & HEAT_CF_FLAG_SAMPLING_CALL) ? 1u : 0u;
+    a.lr = e->lr;
+    a.clip = e->cfg.clip_val;
+    a.key = epoch_key(e->cfg.seed, e->epoch);
+    a.sample_base = e->cfg.sample_index_base;
+    a.ext_negs = nullptr;
+    a.neg_out = nullptr;
+    a.loss_part = e->d_loss_part;
+    return a;
+}
+
+void destroy_impl(heat_cf_engine* e)
+{
+    if (!e) return;
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    for (auto& q : e->ev_pending) { (void)hipEventDestroy(q.a); (void)hipEventDestroy(q.b); }
+    for (auto& q : e->ev_free) { (void)hipEventDestroy(q.a); (void)hipEventDestroy(q.b); }
+    if (e->own_tables)
+    {
+        (void)hipFree(e->d_user_w);
+        (void)hipFree(e->d_item_w);
+        (void)hipFree(e->d_w0);
+    }
+    (void)hipFree(e->d_user_g);
+    (void)hipFree(e->d_item_g);
+    (void)hipFree(e->d_clicks);
+    (void)hipFree(e->d_loss_part);
+    (void)hipFree(e->d_sums);
+    (void)hipFree(e->d_ext_negs);
+    (void)hipFree(e->d_stats);
+    if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+}
+} // namespace
+
+extern "C" {
+
+int heat_cf_abi_version(void) { return HEAT_CF_ABI_VERSION; }
+
+const char* heat_cf_last_error(void) { return g_last_error.c_str(); }
+
+int heat_cf_device_count(void)
+{
+    int n = 0;
+    hipError_t err = hipGetDeviceCount(&n);
+    if (err != hipSuccess) return fail(HEAT_CF_EHIP, std::string("hipGetDeviceCount: ") + hipGetErrorString(err));
+    return n;
+}
+
+int heat_cf_engine_create(const heat_cf_config* cfg, const uint64_t* clicks, uint64_t data_rows, const uint64_t* his,
+                          uint64_t max_his, const uint64_t* masks, float* user_w, float* item_w, float* w0,
+                          heat_cf_engine** out)
+{
+    (void)his; (void)max_his; (void)masks;
+    if (!out) return fail(HEAT_CF_EINVAL, "out is NULL");
+    *out = nullptr;
+    int lpr = 0, ng = 0;
+    int rc = validate_cfg(cfg, data_rows, &lpr, &ng);
+    if (rc) return rc;
+    if (!clicks && data_rows) return fail(HEAT_CF_EINVAL, "clicks is NULL");
+    if (!user_w || !item_w) return fail(HEAT_CF_EINVAL, "user_w / item_w is NULL");
+    // range check + pack to u32 pairs (the reference performs no bounds checks; on a GPU an out-of-range id
+    // is a memory fault, so it is rejected here)
+    std::vector<uint2> packed;
+    try { packed.resize(data_rows); }
+    catch (const std::bad_alloc&) { return fail(HEAT_CF_ENOMEM, "host allocation failed"); }
+    for (uint64_t i = 0; i < data_rows; ++i)
+    {
+        const uint64_t u = clicks[2 * i], it = clicks[2 * i + 1];
+        if (u >= cfg->num_users || it >= cfg->num_items)
+            return fail(HEAT_CF_EINVAL, "click_dataset row " + std::to_string(i) + " has an id out of range");
+        packed[i] = make_uint2((uint32_t)u, (uint32_t)it);
+    }
+    heat_cf_engine* e = new (std::nothrow) heat_cf_engine();
+    if (!e) return fail(HEAT_CF_ENOMEM, "host allocation failed");
+    e->lpr = lpr;
+    e->ng = ng;
+    e->host_mode = true;
+    e->h_user_w = user_w;
+    e->h_item_w = item_w;
+    e->h_w0 = w0;
+#define CREATE_TRY(expr)            \
+    do                              \
+    {                               \
+        int _rc = (expr);           \
+        if (_rc)                    \
+        {                           \
+            destroy_impl(e);        \
+            return _rc;             \
+        }                           \
+    } while (0)
+    CREATE_TRY(common_init(e, cfg, data_rows, nullptr));
+    auto body = [&]() -> int {
+        e->own_tables = true;
+        HIP_TRY(hipMalloc(&e->d_user_w, std::max<size_t>(user_bytes(e), 16)));
+        HIP_TRY(hipMalloc(&e->d_item_w, std::max<size_t>(item_bytes(e), 16)));
+        HIP_TRY(hipMalloc(&e->d_user_g, std::max<size_t>(user_bytes(e), 16)));
+        HIP_TRY(hipMalloc(&e->d_item_g, std::max<size_t>(item_bytes(e), 16)));
+        HIP_TRY(hipMalloc(&e->d_clicks, std::max<size_t>(data_rows * sizeof(uint2), 16)));
+        HIP_TRY(hipMemcpyAsync(e->d_user_w, user_w, user_bytes(e), hipMemcpyHostToDevice, e->stream));
+        HIP_TRY(hipMemcpyAsync(e->d_item_w, item_w, item_bytes(e), hipMemcpyHostToDevice, e->stream));
+        HIP_TRY(hipMemcpyAsync(e->d_clicks, packed.data(), data_rows * sizeof(uint2), hipMemcpyHostToDevice, e->stream));
+        // embeddings/embedding.cpp:12-13 + memory/array.hpp:22-24: owned, zero-initialised gradient tables
+        HIP_TRY(hipMemsetAsync(e->d_user_g, 0, user_bytes(e), e->stream));
+        HIP_TRY(hipMemsetAsync(e->d_item_g, 0, item_bytes(e), e->stream));
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        return HEAT_CF_OK;
+    };
+    CREATE_TRY(body());
+    *out = e;
+    return HEAT_CF_OK;
+}
+
+int heat_cf_engine_create_device(const heat_cf_config* cfg, const void* d_clicks, uint64_t data_rows, const void* d_his,
+                                 uint64_t max_his, const void* d_masks, void* d_user_w, void* d_item_w, void* d_w0,
+                                 void* stream, heat_cf_engine** out)
+{
+    (void)d_his; (void)max_his; (void)d_masks;
+    if (!out) return fail(HEAT_CF_EINVAL, "out is NULL");
+    *out = nullptr;
+    int lpr = 0, ng = 0;
+    int rc = validate_cfg(cfg, data_rows, &lpr, &ng);
+    if (rc) return rc;
+    if (!d_clicks && data_rows) return fail(HEAT_CF_EINVAL, "d_clicks is NULL");
+    if (!d_user_w || !d_item_w) return fail(HEAT_CF_EINVAL, "d_user_w / d_item_w is NULL");
+    if (((uintptr_t)d_user_w | (uintptr_t)d_item_w) & 15u) return fail(HEAT_CF_EINVAL, "tables must be 16-byte aligned");
+    heat_cf_engine* e = new (std::nothrow) heat_cf_engine();
+    if (!e) return fail(HEAT_CF_ENOMEM, "host allocation failed");
+    e->lpr = lpr;
+    e->ng = ng;
+    e->host_mode = false;
+    CREATE_TRY(common_init(e, cfg, data_rows, stream));
+    auto body = [&]() -> int {
+        e->own_tables = false;
+        e->d_user_w = (float*)d_user_w;
+        e->d_item_w = (float*)d_item_w;
+        e->d_w0 = (float*)d_w0;
+        HIP_TRY(hipMalloc(&e->d_user_g, std::max<size_t>(user_bytes(e), 16)));
+        HIP_TRY(hipMalloc(&e->d_item_g, std::max<size_t>(item_bytes(e), 16)));
+        HIP_TRY(hipMalloc(&e->d_clicks, std::max<size_t>(data_rows * sizeof(uint2), 16)));
+        HIP_TRY(hipMemsetAsync(e->d_user_g, 0, user_bytes(e), e->stream));
+        HIP_TRY(hipMemsetAsync(e->d_item_g, 0, item_bytes(e), e->stream));
+        HIP_TRY(hipMemsetAsync(e->d_stats, 0, 4 * sizeof(uint32_t), e->stream));
+        HIP_TRY(launch_pack_clicks((const uint64_t*)d_clicks, e->d_clicks, data_rows, e->d_stats, e->stream));
+        uint32_t stats[4] = {0, 0, 0, 0};
+        HIP_TRY(hipMemcpyAsync(stats, e->d_stats, sizeof(stats), hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        if (data_rows && (stats[2] || stats[0] >= cfg->num_users || stats[1] >= cfg->num_items))
+            return fail(HEAT_CF_EINVAL, "click_dataset holds an id out of range");
+        return HEAT_CF_OK;
+    };
+    CREATE_TRY(body());
+    *out = e;
+    return HEAT_CF_OK;
+}
+
+void heat_cf_engine_destroy(heat_cf_engine* e) { destroy_impl(e); }
+
+int heat_cf_begin_epoch(heat_cf_engine* e)
+{
+    if (!e) return fail(HEAT_CF_EINVAL, "engine is NULL");
+    HIP_TRY(hipSetDevice(e->device));
+    // train/engine.cpp:156-160 with optimizers/optimizer.cpp:24-38 (gamma = 0.1)
+    if (e->milestones.size() > 1)
+    {
+        if (std::find(e->milestones.begin(), e->milestones.end(), e->epoch) != e->milestones.end()) e->lr = e->lr * 0.1f;
+    }
+    else
+    {
+        const uint64_t step = e->milestones[0];
+        if (e->epoch > 0 && e->epoch % step == 0) e->lr = e->lr * 0.1f;
+    }
+    HIP_TRY(hipMemsetAsync(e->d_sums, 0, 2 * sizeof(double), e->stream));
+    return HEAT_CF_OK;
+}
+
+int heat_cf_train_range(heat_cf_engine* e, uint64_t begin, uint64_t end, const uint64_t* neg_ids, double* loss_sum)
+{
+    if (!e) return fail(HEAT_CF_EINVAL, "engine is NULL");
+    if (begin > end || end > e->data_rows) return fail(HEAT_CF_EINVAL, "interaction range out of bounds");
+    HIP_TRY(hipSetDevice(e->device));
+    const uint64_t n = end - begin;
+    if (n == 0)
+    {
+        if (loss_sum) *loss_sum = 0.0;
+        return HEAT_CF_OK;
+    }
+    uint64_t per_block = 0;
+    uint32_t grid = 0;
+    geometry(e, n, &per_block, &grid);
+    int rc = ensure_loss_part(e, grid);
+    if (rc) return rc;
+    TrainArgs a = make_args(e, begin, end);
+    a.per_block = per_block;
+    if (neg_ids)
+    {
+        const size_t cnt = (size_t)n * e->cfg.num_negs;
+        std::vector<uint32_t> tmp(cnt);
+        for (size_t i = 0; i < cnt; ++i)
+        {
+            if (neg_ids[i] >= e->cfg.num_items) return fail(HEAT_CF_EINVAL, "neg_ids holds an id out of range");
+            tmp[i] = (uint32_t)neg_ids[i];
+        }
+        if (cnt > e->ext_cap)
+        {
+            HIP_TRY(hipStreamSynchronize(e->stream));
+            if (e->d_ext_negs) HIP_TRY(hipFree(e->d_ext_negs));
+            e->d_ext_negs = nullptr;
+            HIP_TRY(hipMalloc(&e->d_ext_negs, cnt * sizeof(uint32_t)));
+            e->ext_cap = cnt;
+        }
+        HIP_TRY(hipMemcpyAsync(e->d_ext_negs, tmp.data(), cnt * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
+        HIP_TRY(hipStreamSynchronize(e->stream)); // tmp goes out of scope
+        a.ext_negs = e->d_ext_negs;
+        a.ext_base = begin;
+    }
+    EventPair ev;
+    rc = get_events(e, &ev);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(ev.a, e->stream));
+    HIP_TRY(launch_train(a, e->lpr, e->ng, grid, e->aux, e->stream));
+    HIP_TRY(hipEventRecord(ev.b, e->stream));
+    e->ev_pending.push_back(ev);
+    e->launches += 1;
+    HIP_TRY(hipMemsetAsync(e->d_sums + 1, 0, sizeof(double), e->stream));
+    HIP_TRY(launch_loss_reduce(e->d_loss_part, grid, e->d_sums + 1, e->stream));
+    HIP_TRY(launch_loss_reduce(e->d_loss_part, grid, e->d_sums, e->stream));
+    if (loss_sum)
+    {
+        HIP_TRY(hipMemcpyAsync(loss_sum, e->d_sums + 1, sizeof(double), hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(hipStreamSynchronize(e->stream));
+    }
+    return HEAT_CF_OK;
+}
+
+int heat_cf_zero_grad(heat_cf_engine* e)
+{
+    if (!e) return fail(HEAT_CF_EINVAL, "engine is NULL");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipMemsetAsync(e->d_user_g, 0, user_bytes(e), e->stream));
+    HIP_TRY(hipMemsetAsync(e->d_item_g, 0, item_bytes(e), e->stream));
+    return HEAT_CF_OK;
+}
+
+int heat_cf_end_epoch(heat_cf_engine* e)
+{
+    if (!e) return fail(HEAT_CF_EINVAL, "engine is NULL");
+    int rc = heat_cf_zero_grad(e); // train/engine.cpp:345-347
+    if (rc) return rc;
+    e->epoch += 1;                 // :378
+    if (e->host_mode && !(e->cfg.flags & HEAT_CF_FLAG_LAZY_SYNC)) return heat_cf_sync_to_host(e);
+    return HEAT_CF_OK;
+}
+
+int heat_cf_train_one_epoch(heat_cf_engine* e, float* mean_loss)
+{
+    if (!e) return fail(HEAT_CF_EINVAL, "engine is NULL");
+    int rc = heat_cf_begin_epoch(e);
+    if (rc) return rc;
+    rc = heat_cf_train_range(e, 0, e->data_rows, nullptr, nullptr);
+    if (rc) return rc;
+    double sum = 0.0;
+    HIP_TRY(hipMemcpyAsync(&sum, e->d_sums, sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    rc = heat_cf_end_epoch(e);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    if (mean_loss) *mean_loss = e->data_rows ? (float)(sum / (double)e->data_rows) : 0.0f; // :383-385
+    return HEAT_CF_OK;
+}
+
+int heat_cf_sample_negatives(heat_cf_engine* e, uint64_t begin, uint64_t end, uint64_t* out)
+{
+    if (!e) return fail(HEAT_CF_EINVAL, "engine is NULL");
+    if (begin > end || end > e->data_rows || !out) return fail(HEAT_CF_EINVAL, "bad range / out");
+    if (e->cfg.num_negs > 256) return fail(HEAT_CF_EUNSUP, "num_negs > 256");
+    HIP_TRY(hipSetDevice(e->device));
+    const uint64_t n = end - begin;
+    if (n == 0) return HEAT_CF_OK;
+    uint64_t per_block = 0;
+    uint32_t grid = 0;
+    geometry(e, n, &per_block, &grid);
+    TrainArgs a = make_args(e, begin, end);
+    a.per_block = per_block;
+    uint64_t* d_out = nullptr;
+    const size_t bytes = (size_t)n * e->cfg.num_negs * sizeof(uint64_t);
+    HIP_TRY(hipMalloc(&d_out, bytes));
+    hipError_t err = launch_sample_negs(a, grid, begin, d_out, e->stream);
+    if (err == hipSuccess) err = hipMemcpyAsync(out, d_out, bytes, hipMemcpyDeviceToHost, e->stream);
+    if (err == hipSuccess) err = hipStreamSynchronize(e->stream);
+    (void)hipFree(d_out);
+    HIP_TRY(err);
+    return HEAT_CF_OK;
+}
+
+int heat_cf_evaluate0(heat_cf_engine* e, float* sim)
+{
+    if (!e || !sim) return fail(HEAT_CF_EINVAL, "engine / sim is NULL");
+    HIP_TRY(hipSetDevice(e->device));
+    const uint64_t U = e->cfg.num_users, I = e->cfg.num_items;
+    // row panels keep the device scratch bounded (the full matrix is 19.3 GB at AmazonBooks shape, README.md:104)
+    const uint64_t panel = std::max<uint64_t>(1, std::min<uint64_t>(U, (1ull << 30) / (I * sizeof(float)) + 1));
+    float* d_panel = nullptr;
+    HIP_TRY(hipMalloc(&d_panel, (size_t)panel * I * sizeof(float)));
+    hipError_t err = hipSuccess;
+    for (uint64_t u0 = 0; u0 < U && err == hipSuccess; u0 += panel)
+    {
+        const uint64_t rows = std::min(panel, U - u0);
+        err = launch_sim_panel(e->d_user_w + u0 * e->cfg.emb_dim, e->d_item_w, d_panel, (uint32_t)rows, (uint32_t)I,
+                               (uint32_t)e->cfg.emb_dim, e->stream);
+        if (err == hipSuccess)
+            err = hipMemcpyAsync(sim + u0 * I, d_panel, (size_t)rows * I * sizeof(float), hipMemcpyDeviceToHost, e->stream);
+        if (err == hipSuccess) err = hipStreamSynchronize(e->stream);
+    }
+    (void)hipFree(d_panel);
+    HIP_TRY(err);
+    return HEAT_CF_OK;
+}
+
+int heat_cf_topk(heat_cf_engine* e, uint64_t u_begin, uint64_t u_end, uint32_t k, const uint64_t* mask_indptr,
+                 const uint32_t* mask_items, uint32_t* topk)
+{
+    if (!e || !topk) return fail(HEAT_CF_EINVAL, "engine / topk is NULL");
+    if (u_begin > u_end || u_end > e->cfg.num_users) return fail(HEAT_CF_EINVAL, "user range out of bounds");
+    if (k == 0 || k > e->cfg.num_items) return fail(HEAT_CF_EINVAL, "k must be in [1, num_items]");
+    if (mask_indptr && !mask_items) return fail(HEAT_CF_EINVAL, "mask_items is NULL");
+    HIP_TRY(hipSetDevice(e->device));
+    const uint64_t nu = u_end - u_begin;
+    if (nu == 0) return HEAT_CF_OK;
+    const uint64_t I = e->cfg.num_items, d = e->cfg.emb_dim;
+    const uint64_t panel = std::max<uint64_t>(1, std::min<uint64_t>(nu, (1ull << 30) / (I * sizeof(float)) + 1));
+    float*    d_panel = nullptr;
+    uint64_t* d_indptr = nullptr;
+    uint32_t* d_items = nullptr;
+    uint32_t* d_topk = nullptr;
+    std::vector<uint64_t> rel;
+    hipError_t err = hipMalloc(&d_panel, (size_t)panel * I * sizeof(float));
+    if (err == hipSuccess) err = hipMalloc(&d_topk, (size_t)panel * k * sizeof(uint32_t));
+    if (err == hipSuccess && mask_indptr) err = hipMalloc(&d_indptr, (panel + 1) * sizeof(uint64_t));
+    int rc = HEAT_CF_OK;
+    size_t items_cap = 0;
+    for (uint64_t p0 = 0; p0 < nu && err == hipSuccess && rc == HEAT_CF_OK; p0 += panel)
+    {
+        const uint64_t rows = std::min(panel, nu - p0);
+        const uint64_t ug = u_begin + p0;
+        err = launch_sim_panel(e->d_user_w + ug * d, e->d_item_w, d_panel, (uint32_t)rows, (uint32_t)I, (uint32_t)d, e->stream);
+        if (err == hipSuccess && mask_indptr)
+        {
+            const uint64_t lo = mask_indptr[ug], hi = mask_indptr[ug + rows];
+            if (hi < lo) { rc = fail(HEAT_CF_EINVAL, "mask_indptr must be non-decreasing"); break; }
+            for (uint64_t i = lo; i < hi; ++i)
+                if (mask_items[i] >= I) { rc = fail(HEAT_CF_EINVAL, "mask_items holds an id out of range"); break; }
+            if (rc) break;
+            rel.resize(rows + 1);
+            for (uint64_t u = 0; u <= rows; ++u)
+            {
+                if (mask_indptr[ug + u] < lo || mask_indptr[ug + u] > hi) { rc = fail(HEAT_CF_EINVAL, "mask_indptr must be non-decreasing"); break; }
+                rel[u] = mask_indptr[ug + u] - lo;
+            }
+            if (rc) break;
+            if ((hi - lo) > items_cap)
+            {
+                (void)hipStreamSynchronize(e->stream);
+                (void)hipFree(d_items);
+                d_items = nullptr;
+                items_cap = (size_t)(hi - lo);
+                err = hipMalloc(&d_items, items_cap * sizeof(uint32_t));
+            }
+            if (err == hipSuccess) err = hipMemcpyAsync(d_indptr, rel.data(), (rows + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, e->stream);
+            if (err == hipSuccess && hi > lo)
+                err = hipMemcpyAsync(d_items, mask_items + lo, (hi - lo) * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream);
+            if (err == hipSuccess && hi > lo) err = launch_mask_panel(d_panel, (uint32_t)rows, (uint32_t)I, d_indptr, d_items, e->stream);
+        }
+        if (err == hipSuccess) err = launch_topk_rows(d_panel, (uint32_t)rows, (uint32_t)I, k, d_topk, e->stream);
+        if (err == hipSuccess)
+            err = hipMemcpyAsync(topk + p0 * k, d_topk, (size_t)rows * k * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream);
+        if (err == hipSuccess) err = hipStreamSynchronize(e->stream);
+    }
+    (void)hipStreamSynchronize(e->stream);
+    (void)hipFree(d_panel);
+    (void)hipFree(d_indptr);
+    (void)hipFree(d_items);
+    (void)hipFree(d_topk);
+    if (rc) return rc;
+    HIP_TRY(err);
+    return HEAT_CF_OK;
+}
+
+int heat_cf_sync_to_host(heat_cf_engine* e)
+{
+    if (!e) return fail(HEAT_CF_EINVAL, "engine is NULL");
+    if (!e->host_mode) return HEAT_CF_OK;
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipMemcpyAsync(e->h_user_w, e->d_user_w, user_bytes(e), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipMemcpyAsync(e->h_item_w, e->d_item_w, item_bytes(e), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return HEAT_CF_OK;
+}
+
+int heat_cf_sync_from_host(heat_cf_engine* e)
+{
+    if (!e) return fail(HEAT_CF_EINVAL, "engine is NULL");
+    if (!e->host_mode) return HEAT_CF_OK;
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipMemcpyAsync(e->d_user_w, e->h_user_w, user_bytes(e), hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipMemcpyAsync(e->d_item_w, e->h_item_w, item_bytes(e), hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return HEAT_CF_OK;
+}
+
+int heat_cf_synchronize(heat_cf_engine* e)
+{
+    if (!e) return fail(HEAT_CF_EINVAL, "engine is NULL");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return HEAT_CF_OK;
+}
+
+int heat_cf_get_device_view(heat_cf_engine* e, heat_cf_device_view* view)
+{
+    if (!e || !view) return fail(HEAT_CF_EINVAL, "engine / view is NULL");
+    view->user_w = e->d_user_w;
+    view->item_w = e->d_item_w;
+    view->user_g = e->d_user_g;
+    view->item_g = e->d_item_g;
+    view->w0 = e->d_w0;
+    view->clicks = e->d_clicks;
+    view->data_rows = e->data_rows;
+    view->stream = (void*)e->stream;
+    return HEAT_CF_OK;
+}
+
+uint64_t heat_cf_epoch(const heat_cf_engine* e) { return e ? e->epoch : 0; }
+float    heat_cf_learning_rate(const heat_cf_engine* e) { return e ? e->lr : 0.f; }
+
+int heat_cf_set_learning_rate(heat_cf_engine* e, float l_r)
+{
+    if (!e) return fail(HEAT_CF_EINVAL, "engine is NULL");
+    e->lr = l_r;
+    return HEAT_CF_OK;
+}
+
+int heat_cf_set_epoch(heat_cf_engine* e, uint64_t epoch)
+{
+    if (!e) return fail(HEAT_CF_EINVAL, "engine is NULL");
+    e->epoch = epoch;
+    return HEAT_CF_OK;
+}
+
+int heat_cf_kernel_time(heat_cf_engine* e, double* total_ms, uint64_t* launches, int reset)
+{
+    if (!e) return fail(HEAT_CF_EINVAL, "engine is NULL");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    for (auto& q : e->ev_pending)
+    {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, q.a, q.b));
+        e->kernel_ms += ms;
+        e->ev_free.push_back(q);
+    }
+    e->ev_pending.clear();
+    if (total_ms) *total_ms = e->kernel_ms;
+    if (launches) *launches = e->launches;
+    if (reset)
+    {
+        e->kernel_ms = 0.0;
+        e->launches = 0;
+    }
+    return HEAT_CF_OK;
+}
+
+const char* heat_cf_kernel_name(const heat_cf_engine* e) { return e ? e->kname : ""; }
+
+} // extern "C"

@@ -1,0 +1,180 @@
+/* heat_cf.h — C ABI of the MI355X-native SimpleX/CCL collaborative-filtering training engine.
+ *
+ * This is the drop-in boundary for ONE hot path of visuOwO/HEAT: the per-interaction fused
+ * forward+backward+clipped-SGD step and its epoch loop.  Every entry point cites the reference
+ * interface it replaces (paths relative to /root/reference/cf_cpu/src).  The reference's own
+ * boundary is the pybind11 module `cf_c` (pybind/init_modules.cpp:13-152); heat_amd/csrc/cf_c_module.cpp
+ * re-creates that module on top of this ABI, and INTEGRATION.md shows the binding a HEAT maintainer
+ * would add.
+ *
+ * Conventions
+ *   - plain C types only; all functions return 0 on success, a negative HEAT_CF_E* code on error;
+ *     heat_cf_last_error() returns a thread-local human-readable message.
+ *   - ids are uint64 (`idx_t`, splatt/base.h:49-50), values are fp32 (`val_t`, CMakeLists.txt:11).
+ *   - "host mode": the caller's numpy-style host buffers are BORROWED and trained in place, exactly like
+ *     the reference (init_modules.cpp:45-56,74-84; memory/array.hpp:30-34): the engine uploads them once,
+ *     keeps tables resident in HBM, and writes weights back into the same buffers at the end of
+ *     heat_cf_train_one_epoch() (or on heat_cf_sync_to_host()).
+ *   - "device mode": the caller owns device buffers (e.g. torch tensors) and passes raw device pointers;
+ *     nothing is copied; used by bench.py and the multi-GPU driver (RCCL all-reduce on the caller's tensors).
+ *   - The HIP device code is gfx950-only.  There is NO CPU fallback: without a usable GPU every compute
+ *     entry point fails with HEAT_CF_EHIP.
+ */
+#ifndef HEAT_CF_H
+#define HEAT_CF_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HEAT_CF_ABI_VERSION 1
+
+/* error codes */
+#define HEAT_CF_OK        0
+#define HEAT_CF_EINVAL   -1 /* bad argument / shape / dtype-equivalent (-> Python ValueError)   */
+#define HEAT_CF_EHIP     -2 /* HIP runtime error, no device, kernel fault (-> RuntimeError)     */
+#define HEAT_CF_ENOMEM   -3 /* host or device allocation failed                                 */
+#define HEAT_CF_EUNSUP   -4 /* configuration outside the compiled kernel family                 */
+
+/* flags */
+#define HEAT_CF_FLAG_SERIAL        0x1u /* one wave walks all interactions in stored order (parity tests)      */
+#define HEAT_CF_FLAG_LAZY_SYNC     0x2u /* host mode: do not write weights back after every epoch              */
+#define HEAT_CF_FLAG_SAMPLING_CALL 0x4u /* use sampler.sampling() (engine.cpp:333) instead of the live
+                                           ignore_pos_sampling() (engine.cpp:332)                              */
+
+/* cache policy of table-row traffic (see DESIGN.md "Hogwild across XCDs") */
+#define HEAT_CF_COHERENCE_DEFAULT 0 /* engine picks (device-coherent)                                           */
+#define HEAT_CF_COHERENCE_PLAIN   1 /* plain loads/stores: per-XCD L2 copies may diverge inside one launch      */
+#define HEAT_CF_COHERENCE_DEVICE  2 /* sc1 loads + sc1 write-through stores: coherent across the 8 XCDs         */
+
+/* Replaces cf::modules::CFConfig (modules/cf_config.hpp:12-35; bound at pybind/init_modules.cpp:13-33).
+ * The first 13 fields are the reference's, in its constructor order.  The rest are extensions the
+ * reference does not have (it ignores yaml `seed`, main.py:19-124). */
+typedef struct heat_cf_config
+{
+    uint64_t emb_dim;
+    uint64_t num_negs;
+    uint64_t num_users;
+    uint64_t num_items;
+    uint64_t train_size;
+    uint64_t neg_sampler;       /* 0: uniform random, 1: random tiling (cf_config.hpp:27) */
+    uint64_t tile_size;
+    uint64_t refresh_interval;
+    uint64_t num_subepochs;     /* kwarg `num_subepoches`; only the fork's MPI scaffold reads it */
+    float    l2;                /* plumbed, never applied (matrix_factorization.cpp:126,146,165,168) */
+    float    clip_val;
+    const uint64_t* milestones;
+    uint64_t n_milestones;
+    float    l_r;
+    /* ---- extensions ---- */
+    uint64_t seed;              /* negative-sampler seed (yaml `seed`, e.g. 2022) */
+    uint64_t sample_index_base; /* added to the local interaction index in the sampler counter (multi-GPU shards) */
+    uint32_t use_aggregator;    /* 0: MF-CCL (north-star scope); 1: behaviour aggregation (behavior_aggregators.cpp) */
+    uint32_t flags;             /* HEAT_CF_FLAG_* */
+    uint32_t coherence;         /* HEAT_CF_COHERENCE_* */
+    int32_t  device;            /* HIP device ordinal; -1 = current device */
+    uint32_t num_streams;       /* concurrent sequential interaction streams (waves); 0 = auto */
+    uint32_t reserved;
+} heat_cf_config;
+
+typedef struct heat_cf_engine heat_cf_engine;
+
+/* addresses of the device-resident state (for collectives / zero-copy wrapping by the caller) */
+typedef struct heat_cf_device_view
+{
+    void*    user_w;  /* [num_users, emb_dim] fp32 */
+    void*    item_w;  /* [num_items, emb_dim] fp32 */
+    void*    user_g;  /* persistent clipped-gradient rows (embeddings/embedding.cpp:12-13) */
+    void*    item_g;
+    void*    w0;      /* [emb_dim, emb_dim] fp32 or NULL */
+    void*    clicks;  /* [data_rows] packed {u32 user, u32 item} */
+    uint64_t data_rows;
+    void*    stream;  /* hipStream_t the engine launches on */
+} heat_cf_device_view;
+
+int         heat_cf_abi_version(void);
+const char* heat_cf_last_error(void);
+/* number of visible HIP devices, or a negative error code */
+int         heat_cf_device_count(void);
+
+/* Replaces the constructors bound at pybind/init_modules.cpp:45-59 (ClickDataset), :74-84
+ * (MatrixFactorization), :95-99 (AggregatorWeights) and :109-116 (Engine) — one call builds the whole
+ * training state.  HOST pointers, borrowed:
+ *   clicks [data_rows,2] u64 (user,item) in LightGCN order (datasets.py:63-67)
+ *   his    [num_users,max_his] u64, masks [num_users,1] u64   (may be NULL when use_aggregator == 0)
+ *   user_w [num_users,emb_dim], item_w [num_items,emb_dim] fp32, trained IN PLACE
+ *   w0     [emb_dim,emb_dim] fp32 (may be NULL when use_aggregator == 0)
+ * Ids are range-checked here (the reference does not check; an out-of-range id on a GPU is a fault). */
+int heat_cf_engine_create(const heat_cf_config* cfg, const uint64_t* clicks, uint64_t data_rows,
+                          const uint64_t* his, uint64_t max_his, const uint64_t* masks, float* user_w,
+                          float* item_w, float* w0, heat_cf_engine** out);
+
+/* Device-mode twin: every pointer is a DEVICE pointer owned by the caller (clicks still u64 pairs, they are
+ * packed to u32 pairs into engine-owned memory and range-checked on the GPU).  `stream` is a hipStream_t
+ * (NULL = the engine creates its own non-blocking stream). */
+int heat_cf_engine_create_device(const heat_cf_config* cfg, const void* d_clicks, uint64_t data_rows,
+                                 const void* d_his, uint64_t max_his, const void* d_masks, void* d_user_w,
+                                 void* d_item_w, void* d_w0, void* stream, heat_cf_engine** out);
+
+void heat_cf_engine_destroy(heat_cf_engine* e);
+
+/* Replaces Engine::train_one_epoch() (train/engine.hpp:29; semantics = upstream OpenMP body
+ * train/engine.cpp:294-342 + LR schedule :156-160 + zero_grad :345-347 + mean loss :380-385):
+ * LR step for the current epoch, one pass over all interactions, zero both G tables, epoch += 1,
+ * host mode: weights written back into the borrowed buffers.  *mean_loss = sum(loss)/data_rows. */
+int heat_cf_train_one_epoch(heat_cf_engine* e, float* mean_loss);
+
+/* The same epoch cut into pieces (multi-GPU windows, parity tests):
+ *   begin_epoch : LR schedule (engine.cpp:156-160)
+ *   train_range : interactions [begin,end) in stored order.  neg_ids (HOST, [end-begin, num_negs] u64, may be
+ *                 NULL) overrides the on-GPU sampler with caller-fed negatives.  Asynchronous on the engine's
+ *                 stream unless loss_sum != NULL (then it synchronises and returns the fp64 loss sum).
+ *   end_epoch   : zero_grad (engine.cpp:345-347), epoch += 1 (:378), host-mode write-back.  */
+int heat_cf_begin_epoch(heat_cf_engine* e);
+int heat_cf_train_range(heat_cf_engine* e, uint64_t begin, uint64_t end, const uint64_t* neg_ids, double* loss_sum);
+int heat_cf_end_epoch(heat_cf_engine* e);
+
+/* Negatives the on-GPU sampler (Philox4x32-10, counter = interaction index) yields for interactions
+ * [begin,end) of the CURRENT epoch, written to HOST out[(end-begin), num_negs] u64.  Replaces nothing in the
+ * reference API; it exposes negative_samplers/uniform_random_negative_sampler.cpp:26-36 semantics for tests. */
+int heat_cf_sample_negatives(heat_cf_engine* e, uint64_t begin, uint64_t end, uint64_t* out);
+
+/* Replaces Engine::evaluate0() + the PyMatrix copy (train/engine.cpp:388-400, pybind/init_modules.cpp:122-129):
+ * sim[num_users,num_items] = U * V^T, fp32, written to HOST memory. */
+int heat_cf_evaluate0(heat_cf_engine* e, float* sim);
+
+/* Fused evaluate0 + train-mask + top-k (metrics.py:21-29): for users [u_begin,u_end) writes
+ * the k best item ids (descending score) to HOST topk[(u_end-u_begin), k] u32.  mask_indptr/mask_items is the
+ * CSR of train items per user (HOST, may be NULL = no masking). */
+int heat_cf_topk(heat_cf_engine* e, uint64_t u_begin, uint64_t u_end, uint32_t k, const uint64_t* mask_indptr,
+                 const uint32_t* mask_items, uint32_t* topk);
+
+/* host <-> device weight copies (host mode only; no-ops in device mode) */
+int heat_cf_sync_to_host(heat_cf_engine* e);
+int heat_cf_sync_from_host(heat_cf_engine* e);
+/* blocks until everything queued on the engine's stream has finished */
+int heat_cf_synchronize(heat_cf_engine* e);
+
+int heat_cf_get_device_view(heat_cf_engine* e, heat_cf_device_view* view);
+
+/* scalar state */
+uint64_t heat_cf_epoch(const heat_cf_engine* e);
+float    heat_cf_learning_rate(const heat_cf_engine* e);
+int      heat_cf_set_learning_rate(heat_cf_engine* e, float l_r);
+int      heat_cf_set_epoch(heat_cf_engine* e, uint64_t epoch);
+/* zero both persistent gradient tables (embeddings/embedding.cpp:41-45) */
+int      heat_cf_zero_grad(heat_cf_engine* e);
+
+/* Timing of the training kernel(s), measured with HIP events on the engine's stream:
+ * accumulated kernel milliseconds and launch count since the last reset. */
+int heat_cf_kernel_time(heat_cf_engine* e, double* total_ms, uint64_t* launches, int reset);
+/* name of the kernel variant the engine dispatches for its configuration (for profiles/) */
+const char* heat_cf_kernel_name(const heat_cf_engine* e);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HEAT_CF_H */
