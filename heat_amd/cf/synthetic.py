@@ -39,6 +39,8 @@ def make_graph(num_users, num_items, train_size, seed=2022, test_frac=0.2, zipf_
         raise ValueError("train_size must be >= num_users (every user keeps at least one train item)")
     rng = np.random.default_rng(seed)
     total = int(round(train_size / (1.0 - test_frac))) if with_test else train_size
+    if total > 0.25 * num_users * num_items:
+        raise ValueError("graph too dense: (user,item) pairs are unique, ask for <= 25% of num_users*num_items")
     # degrees: clipped Pareto rescaled to the target mean
     raw = rng.pareto(deg_alpha, size=num_users) + 1.0
     cap = max(min_deg + 1, min(num_items // 4, int(40 * total / num_users)))

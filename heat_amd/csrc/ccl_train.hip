@@ -166,6 +166,7 @@ __global__ __launch_bounds__(64) void ccl_train_kernel(TrainArgs a)
                         const uint32_t o = lane_get(cmax, lane ^ m);
                         cmax = o > cmax ? o : cmax;
                     }
+                    cmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)cmax); // provably uniform loop bound
                 }
                 else
                 {

@@ -11,7 +11,13 @@ from tests import philox_ref
 pytestmark = pytest.mark.gpu
 
 
-def small_problem(U, I, T, d, seed, scale=0.01):
+# Conditioning note (DESIGN.md "Parity"): at the reference's own hyper-parameters (N(0,0.01^2) init, lr 0.01, clip 1.0)
+# one update moves an element by up to lr*clip = 0.01 = the embedding scale and the un-clipped coordinates have
+# d(grad)/dW ~ lg/|u|^2 ~ 2000, i.e. lr * d(grad)/dW >> 1: two fp32 implementations that differ in the last bit
+# (Eigen vs this oracle vs the GPU) separate exponentially and are O(1) apart after a few hundred dependent steps.
+# Trajectory-level comparisons therefore run in a well-conditioned regime (scale 0.1: lr * d(grad)/dW ~ 0.2), where
+# thousands of dependent steps agree to ~1e-5; the reference regime is covered over short horizons and statistically.
+def small_problem(U, I, T, d, seed, scale=0.1):
     rng = np.random.default_rng(seed)
     g = synthetic.make_graph(U, I, T, seed=seed, with_test=False)
     uw = (rng.standard_normal((U, d)) * scale).astype(np.float32)
@@ -48,7 +54,7 @@ def assert_tables_close(a, b, scale, rtol=2e-4):
     (32, 4, 30, 200, 1500),      # <8,1>
     (256, 16, 20, 300, 600),     # <64,16>
     (64, 5, 30, 200, 1000),      # masked negative slots (N not a multiple of rows-per-instruction)
-    (20, 3, 25, 100, 800),       # masked columns (emb_dim/4 = 5 of 8 lanes)
+    (20, 3, 25, 300, 800),       # masked columns (emb_dim/4 = 5 of 8 lanes)
     (64, 100, 20, 2000, 300),    # <16,25>, two id registers per lane
 ])
 def test_serial_walk_matches_oracle(d, N, U, I, T):
@@ -56,7 +62,7 @@ def test_serial_walk_matches_oracle(d, N, U, I, T):
     rng = np.random.default_rng(1)
     negs = rng.integers(0, I, size=(T, N)).astype(np.uint64)
     (ug, ig, lg), (uo, io, lo) = run_pair(clicks, uw, iw, N, negs)
-    assert abs(lg - lo) <= 1e-4 * abs(lo)
+    assert abs(lg - lo) <= 1e-5 * abs(lo)
     assert_tables_close(ug, uo, scale=np.abs(uo).max())
     assert_tables_close(ig, io, scale=np.abs(io).max())
     assert not np.array_equal(uo, uw)  # something was trained
@@ -67,11 +73,25 @@ def test_collision_heavy_walk_matches_oracle(coherence):
     """17 items only: duplicate negatives, negative == positive and overlaps between consecutive interactions occur
     in almost every step (matrix_factorization.cpp:72-73,147-149,171-174 ordering quirks)."""
     d, N, U, I, T = 64, 16, 10, 17, 1500
-    clicks, uw, iw = small_problem(U, I, T, d, seed=3, scale=0.1)
     rng = np.random.default_rng(2)
+    clicks = np.stack([np.sort(rng.integers(0, U, T)), rng.integers(0, I, T)], axis=1).astype(np.uint64)
+    uw = (rng.standard_normal((U, d)) * 0.1).astype(np.float32)
+    iw = (rng.standard_normal((I, d)) * 0.1).astype(np.float32)
     negs = rng.integers(0, I, size=(T, N)).astype(np.uint64)  # positives allowed among negatives
-    (ug, ig, lg), (uo, io, lo) = run_pair(clicks, uw, iw, N, negs, clip=0.05, lr=0.05, coherence=coherence)
+    (ug, ig, lg), (uo, io, lo) = run_pair(clicks, uw, iw, N, negs, clip=0.05, lr=0.01, coherence=coherence)
     assert abs(lg - lo) <= 2e-4 * abs(lo)
+    assert_tables_close(ug, uo, scale=np.abs(uo).max(), rtol=5e-4)
+    assert_tables_close(ig, io, scale=np.abs(io).max(), rtol=5e-4)
+
+
+def test_reference_hyperparameters_short_horizon():
+    """N(0,0.01^2) init, lr 0.01, clip 1.0 (AmazonBooks config0.yaml): 12 dependent steps agree to 1e-4 relative."""
+    d, N, U, I, T = 64, 16, 4, 400, 12
+    clicks, uw, iw = small_problem(U, I, T, d, seed=77, scale=0.01)
+    rng = np.random.default_rng(3)
+    negs = np.stack([rng.choice(I, N, replace=False) for _ in range(T)]).astype(np.uint64)
+    (ug, ig, lg), (uo, io, lo) = run_pair(clicks, uw, iw, N, negs)
+    assert abs(lg - lo) <= 1e-5 * abs(lo)
     assert_tables_close(ug, uo, scale=np.abs(uo).max(), rtol=5e-4)
     assert_tables_close(ig, io, scale=np.abs(io).max(), rtol=5e-4)
 
@@ -134,8 +154,6 @@ def test_epoch_protocol_lr_schedule_zero_grad_and_inplace_weights():
     l1 = eng.train_one_epoch()
     assert abs(eng.l_r - 0.005) < 1e-9                            # StepLR(milestones[0]=1, 0.1) fired at epoch 1
     assert l1 < l0 and np.isfinite(l0) and np.isfinite(l1)
-    # reference loss at init: log(1 + N*exp(~0)) = log(17) = 2.83 for near-orthogonal random embeddings
-    assert 1.0 < l0 < 3.5
     eng.close()
 
 
