@@ -1,0 +1,96 @@
+"""Mirror of the reference's cf/datasets.py:14-107 (ClickDataset) without mpi4py: LightGCN text format
+(`user item item ...` per line), history matrix + masks, interaction list in file order.
+
+Differences from the reference, all deliberate: `random.sample` of the history is seeded (`seed` argument; the
+reference is unseeded, datasets.py:48), parsing is vectorised for large files, and sharding a dataset by user
+range lives in heat_amd.cf.distributed (the fork's SubClickDataset + pickling over MPI is not reproduced)."""
+import random
+
+import numpy as np
+
+from .cpp_base import CPPBase
+
+
+class Dataset(CPPBase):
+    def __init__(self):
+        super().__init__()
+
+
+class ClickDataset(Dataset):
+    def __init__(self, file_path=None, separator=' ', config=None, seed=2022, user_items=None, is_train=None):
+        """file_path: LightGCN txt; or user_items: {user_id: [items]} (synthetic graphs)."""
+        super().__init__()
+        self.file_path = file_path if file_path is not None else "<memory>"
+        self.user_items_dic = {}
+        self.max_his = config.max_his
+        rnd = random.Random(seed)
+        if user_items is None:
+            with open(file_path, mode='r') as in_file:
+                for line in in_file:
+                    splits = line.strip().split(separator)
+                    if not splits or splits[0] == '':
+                        continue
+                    self.user_items_dic[int(splits[0])] = [int(x) for x in splits[1:] if x != '']
+        else:
+            self.user_items_dic = {int(u): [int(i) for i in items] for u, items in user_items.items()}
+        # datasets.py:44-45: one history row per line, indexed by user id (sized by the largest id so that a file
+        # that skips users, e.g. a test split, does not index out of range as the reference would)
+        num_lines = max(len(self.user_items_dic), (max(self.user_items_dic) + 1) if self.user_items_dic else 0)
+        self.his_items = np.zeros((num_lines, self.max_his), dtype=np.uint64)
+        self.masks = np.zeros((num_lines, 1), dtype=np.uint64)
+        item_ids = set()
+        pairs = []
+        for user_id, items in self.user_items_dic.items():
+            if len(items) >= self.max_his:                       # datasets.py:58-61
+                self.his_items[user_id] = rnd.sample(items, self.max_his)
+                self.masks[user_id] = self.max_his
+            elif len(items) > 0:                                 # :62-66 pad with the last item
+                self.his_items[user_id] = items + [items[-1]] * (self.max_his - len(items))
+                self.masks[user_id] = len(items)
+            else:                                                # :67-72
+                print(f"Warning {user_id} has 0 items !!! ")
+            item_ids.update(items)
+            pairs.extend((user_id, it) for it in items)          # :74-78 interactions in file order
+        self.user_item_ids = pairs
+        self.num_users = len(self.user_items_dic)
+        self.num_items = len(item_ids)
+        self._min_max = (min(self.user_items_dic) if self.user_items_dic else 0,
+                         max(self.user_items_dic) if self.user_items_dic else 0,
+                         min(item_ids) if item_ids else 0, max(item_ids) if item_ids else 0)
+        self.gen_dataset_info()
+        train = ('train' in self.file_path) if is_train is None else is_train   # datasets.py:82
+        if train:
+            from heat_amd import cf_c
+            self.c_class = cf_c.modules.datasets.ClickDataset
+            config.num_users = self.num_users
+            config.num_items = self.num_items
+            config.train_size = len(self.user_item_ids)
+            self.click_dataset = np.array(self.user_item_ids, dtype=np.uint64).reshape(-1, 2)
+            self.init_c_instance(click_dataset=self.click_dataset, historical_items=self.his_items, masks=self.masks)
+            self.c_instance.max_his = self.max_his
+
+    def gen_dataset_info(self):
+        lo_u, hi_u, lo_i, hi_i = self._min_max
+        print(f'gen dataset info of {self.file_path} ')
+        if hi_u - lo_u + 1 != self.num_users:
+            print('Warning user_id is not continuous! ')
+        if hi_i - lo_i + 1 != self.num_items:
+            print('Warning item_id is not continuous! ')
+        print(f'number of users: {self.num_users}; min_user_id: {lo_u}; max_user_id: {hi_u}')
+        print(f'number of items: {self.num_items}; min_item_id: {lo_i}; max_item_id: {hi_i}')
+        print(f'total samples: {len(self.user_item_ids)} ')
+
+    def get_user_items(self):
+        return self.user_items_dic
+
+    def train_csr(self):
+        """(indptr u64 [num_users+1], items u32) of this dataset's items per user id — the mask for top-k eval."""
+        n = (max(self.user_items_dic) + 1) if self.user_items_dic else 0
+        lens = np.zeros(n, dtype=np.int64)
+        for u, items in self.user_items_dic.items():
+            lens[u] = len(items)
+        indptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+        items = np.empty(int(indptr[-1]), dtype=np.uint32)
+        for u, its in self.user_items_dic.items():
+            items[int(indptr[u]):int(indptr[u + 1])] = its
+        return indptr, items

@@ -1,0 +1,92 @@
+"""Counterpart of the reference's cf/main.py:19-124 (same yaml keys, same flow, same epoch log line), without
+mpi4py: `python -m heat_amd.cf.main --config <yaml>`.  With `--synthetic <shape>` the LightGCN files named by the
+yaml are replaced by a seeded synthetic graph of that shape (the real datasets are not available offline)."""
+import argparse
+import os
+import time
+
+import numpy as np
+import torch
+
+from . import metrics, synthetic, utils
+from .behavior_aggregators import AggregatorWeights
+from .cf_config import CFConfig
+from .datasets import ClickDataset
+from .models import MatrixFactorization
+from .train import Engine
+
+
+def _graph_to_datasets(graph, cf_config, seed):
+    tr, te = {}, {}
+    ti, tp = graph.train_items, graph.train_indptr.astype(np.int64)
+    ep = graph.test_indptr.astype(np.int64)
+    for u in range(graph.num_users):
+        tr[u] = ti[tp[u]:tp[u + 1]].tolist()
+        if ep[u + 1] > ep[u]:
+            te[u] = graph.test_items[ep[u]:ep[u + 1]].tolist()
+    train = ClickDataset(config=cf_config, seed=seed, user_items=tr, is_train=True)
+    test = ClickDataset(config=cf_config, seed=seed, user_items=te, is_train=False)
+    return train, test
+
+
+def main(argv=None):
+    print('this is main ...')
+    parser = argparse.ArgumentParser()
+    parser.add_argument('--config', type=str, default=os.path.join(os.path.dirname(__file__), 'benchmarks', 'AmazonBooks',
+                                                                   'MF_CCL', 'configs', 'config0.yaml'))
+    parser.add_argument('--synthetic', type=str, default=None, help='amazonbooks | gowalla | yelp18: seeded synthetic graph')
+    parser.add_argument('--scale', type=float, default=1.0)
+    parser.add_argument('--gpu-topk', action='store_true', help='evaluate with the fused GPU top-k instead of evaluate0()')
+    args = parser.parse_args(argv)
+    config_dic = utils.load_config(args.config)
+    dataset_config = config_dic['dataset_config']
+    model_config = config_dic['model_config']
+    print(model_config)
+    seed = int(model_config.get('seed', 2022))      # the reference never reads `seed`; we honour it
+    torch.manual_seed(seed)
+    cf_config = CFConfig(emb_dim=model_config['embedding_dim'], num_negs=model_config['num_negs'],
+                         max_his=model_config['max_his'], neg_sampler=model_config['neg_sampler'],
+                         tile_size=model_config['tile_size'], refresh_interval=model_config['refresh_interval'],
+                         l2=model_config['embedding_regularizer'], clip_val=model_config['clip_val'],
+                         milestones=model_config['milestones'], l_r=model_config['learning_rate'], seed=seed,
+                         use_aggregator=bool(model_config.get('use_aggregator', False)))
+    print('--- Start loading data ---')
+    if args.synthetic:
+        graph, _, _ = synthetic.make_named(args.synthetic, seed=seed, scale=args.scale)
+        train_data, test_data = _graph_to_datasets(graph, cf_config, seed)
+    else:
+        train_file = os.path.join(dataset_config['data_dir'], dataset_config['train_data'])
+        test_file = os.path.join(dataset_config['data_dir'], dataset_config['test_data'])
+        train_data = ClickDataset(train_file, separator=dataset_config['separator'], config=cf_config, seed=seed)
+        test_data = ClickDataset(test_file, separator=dataset_config['separator'], config=cf_config, seed=seed)
+    print('--- Finished loading data ---')
+    cf_config.init_c_instance()
+    aggregator_weights = AggregatorWeights(cf_config)
+    model = MatrixFactorization(cf_config)
+    model.init_c_instance(cf_config)
+    engine = Engine(train_data, aggregator_weights, model, cf_config)
+    eval_interval = model_config['eval_interval']
+    results = {}
+    for epoch in range(model_config['epochs']):
+        start_time = time.time()
+        epoch_loss = engine.train_one_epoch()
+        epoch_time = time.time() - start_time
+        print(f'epoch: {epoch}; loss: {epoch_loss}; epoch_time: {epoch_time}')      # main.py:113
+        if epoch > 0 and epoch % eval_interval == 0:                                # main.py:115
+            print('--- Start evaluation ---')
+            model.eval()
+            with torch.no_grad():
+                eva_metrics = ['Recall(k=20)']                                      # main.py:120
+                if args.gpu_topk:
+                    indptr, items = train_data.train_csr()
+                    top = engine.topk(20, indptr, items)
+                    results = metrics.evaluate_topk(test_data, top, eva_metrics)
+                else:
+                    sim_matrix = engine.evaluate0()
+                    print(f'sim_matrix shape: {np.shape(sim_matrix)} !!! ')
+                    results = metrics.evaluate_metrics(train_data, test_data, sim_matrix, eva_metrics)
+    return results
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,110 @@
+"""Host-side mirror of the reference's cf/metrics.py:5-159 (same metric names, same definitions, same
+`evaluate_metrics(train_data, test_data, sim_matrix, metrics)` entry), pinned to the reference by
+tests/golden/metrics_golden.json.  `evaluate_topk` is the same evaluation from a top-k id matrix (GPU path)."""
+import re
+
+import numpy as np
+
+
+def _parse(metric):
+    m = re.fullmatch(r"\s*([A-Za-z0-9]+)\(k=(\d+)\)\s*", metric)
+    if not m or m.group(1) not in _METRICS:
+        raise NotImplementedError('metrics={} not implemented.'.format(metric))
+    return _METRICS[m.group(1)], int(m.group(2))
+
+
+def _recall(top, true, k):
+    return len(set(true) & set(top[:k])) / (len(true) + 1e-12)                  # metrics.py:44-48
+
+
+def _normalized_recall(top, true, k):
+    return len(set(true) & set(top[:k])) / min(k, len(true) + 1e-12)            # :56-60
+
+
+def _precision(top, true, k):
+    return len(set(true) & set(top[:k])) / (k + 1e-12)                          # :68-72
+
+
+def _f1(top, true, k):
+    p, r = _precision(top, true, k), _recall(top, true, k)
+    return 2 * p * r / (p + r + 1e-12)                                          # :80-84
+
+
+def _dcg(top, true, k):
+    true = set(true)
+    dcg = 0
+    for i, item in enumerate(top[:k]):
+        if item in true:
+            dcg += 1 / np.log(2 + i)                                            # :99 natural log
+    return dcg
+
+
+def _ndcg(top, true, k):
+    idcg = _dcg(true[:k], true, k)                                              # :111 ideal = first k true items
+    return _dcg(top, true, k) / (idcg + 1e-12)
+
+
+def _mrr(top, true, k):
+    true = set(true)
+    mrr = 0
+    for i, item in enumerate(top[:k]):
+        if item in true:
+            mrr += 1 / (i + 1.0)                                                # :125-127 (sum, not first hit)
+    return mrr
+
+
+def _hit_rate(top, true, k):
+    return 1 if len(set(true) & set(top[:k])) > 0 else 0
+
+
+def _map(top, true, k):
+    true = set(true)
+    pos, precision = 0, 0
+    for i, item in enumerate(top[:k]):
+        if item in true:
+            pos += 1
+            precision += pos / (i + 1.0)
+    return precision / (pos + 1e-12)
+
+
+_METRICS = {"Recall": _recall, "NormalizedRecall": _normalized_recall, "Precision": _precision, "F1": _f1,
+            "DCG": _dcg, "NDCG": _ndcg, "MRR": _mrr, "HitRate": _hit_rate, "MAP": _map}
+
+
+def _score(top_k_items, test_items_dic, test_user_ids, metrics, quiet=False):
+    callers = [_parse(m) for m in metrics]
+    true_items = [test_items_dic[u] for u in test_user_ids]
+    # metrics.py:31-32 zips ROW i of the top-k matrix with the i-th test user (not with row `user id`)
+    results = [[fn([int(x) for x in top], true, k) for fn, k in callers] for top, true in zip(top_k_items, true_items)]
+    average_result = np.average(np.array(results), axis=0).tolist()
+    if not quiet:
+        print('[Metrics] ' + ' - '.join('{}: {:.6f}'.format(k, v) for k, v in zip(metrics, average_result)))
+    return dict(zip(metrics, average_result))
+
+
+def evaluate_metrics(train_data, test_data, sim_matrix, metrics, quiet=False):
+    """metrics.py:5-36: mask train items with -inf (in place), argpartition top-k, sort, score per user, average."""
+    if not quiet:
+        print(f'Evaluating metrics {metrics} ...')
+    train_items_dic = train_data.user_items_dic
+    test_items_dic = test_data.user_items_dic
+    test_user_ids = list(test_items_dic.keys())
+    max_top_k = max(_parse(m)[1] for m in metrics)
+    for u in test_user_ids:
+        sim_matrix[u, train_items_dic[u]] = -np.inf                                            # :24
+    item_indices = np.argpartition(-sim_matrix, max_top_k)[:, 0:max_top_k]                      # :26
+    part = sim_matrix[np.arange(item_indices.shape[0])[:, None], item_indices]
+    sorted_ids = np.argsort(-part, axis=1)                                                      # :28
+    top_k_items = item_indices[np.arange(sorted_ids.shape[0])[:, None], sorted_ids]
+    return _score(top_k_items, test_items_dic, test_user_ids, metrics, quiet)
+
+
+def evaluate_topk(test_data, top_k_items, metrics, quiet=False, by_user_id=False):
+    """Same scoring from a [num_users, k] id matrix (e.g. Engine.topk with the train CSR as mask).
+    by_user_id=False reproduces the reference's row pairing (row i <-> i-th test user); True pairs row `u` with user u."""
+    test_items_dic = test_data.user_items_dic
+    test_user_ids = list(test_items_dic.keys())
+    if max(_parse(m)[1] for m in metrics) > top_k_items.shape[1]:
+        raise ValueError("top_k_items holds fewer columns than the largest k requested")
+    rows = top_k_items[np.asarray(test_user_ids, dtype=np.int64)] if by_user_id else top_k_items
+    return _score(rows, test_items_dic, test_user_ids, metrics, quiet)

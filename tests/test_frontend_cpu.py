@@ -1,0 +1,179 @@
+"""CPU tests of the host-side mirror of the reference's Python frontend: metrics against golden vectors generated
+by importing the reference's metrics.py (tests/golden/gen_metrics_golden.py), the LightGCN parser against a
+hand-made fixture, the cf_c module surface and the C-ABI symbol table (no compute calls: there is no GPU here)."""
+import contextlib
+import io
+import json
+import os
+import re
+import types
+
+import numpy as np
+import pytest
+
+from heat_amd.cf import metrics as M
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def metric_cases(golden_dir):
+    with open(os.path.join(golden_dir, "metrics_golden.json")) as f:
+        return json.load(f)["cases"]
+
+
+def test_metrics_match_reference_golden(metric_cases):
+    assert len(metric_cases) >= 10
+    for case in metric_cases:
+        sim = np.asarray(case["sim_bits"], dtype=np.uint32).view(np.float32).reshape(case["shape"]).copy()
+        train = types.SimpleNamespace(user_items_dic={int(k): v for k, v in case["train"].items()})
+        test = types.SimpleNamespace(user_items_dic={int(k): v for k, v in case["test"].items()})
+        got = M.evaluate_metrics(train, test, sim, case["metrics"], quiet=True)
+        for name, want in case["expected"].items():
+            assert got[name] == pytest.approx(want, rel=1e-12, abs=1e-15), name
+
+
+def test_evaluate_topk_equals_dense_path(metric_cases):
+    case = metric_cases[1]
+    sim = np.asarray(case["sim_bits"], dtype=np.uint32).view(np.float32).reshape(case["shape"]).copy()
+    train = {int(k): v for k, v in case["train"].items()}
+    test = types.SimpleNamespace(user_items_dic={int(k): v for k, v in case["test"].items()})
+    masked = sim.copy()
+    for u, items in train.items():
+        masked[u, items] = -np.inf
+    top = np.argsort(-masked, axis=1, kind="stable")[:, :50]
+    got = M.evaluate_topk(test, top, case["metrics"], quiet=True)
+    for name, want in case["expected"].items():
+        assert got[name] == pytest.approx(want, rel=1e-12)
+
+
+def test_unknown_metric_raises():
+    with pytest.raises(NotImplementedError):
+        M.evaluate_topk(types.SimpleNamespace(user_items_dic={0: [1]}), np.zeros((1, 5), int), ["Bogus(k=3)"])
+
+
+def test_cf_c_module_surface():
+    """Names, keyword arguments and attributes of pybind/init_modules.cpp:13-152."""
+    from heat_amd import cf_c
+    m = cf_c.modules
+    for path in ["CFConfig", "datasets.Dataset", "datasets.ClickDataset", "models.Model", "models.MatrixFactorization",
+                 "behavior_aggregators.AggregatorWeights", "train.Engine", "test.test_out"]:
+        obj = m
+        for part in path.split("."):
+            obj = getattr(obj, part)
+    with contextlib.redirect_stdout(io.StringIO()):
+        cfg = m.CFConfig(emb_dim=64, num_negs=16, num_users=4, num_items=10, train_size=12, neg_sampler=0, tile_size=512,
+                         refresh_interval=8192, num_subepoches=2, l2=1e-7, clip_val=1.0, milestones=[10], l_r=0.01)
+    assert cfg.emb_dim == 64
+    cfg.emb_dim = 64
+    assert issubclass(m.datasets.ClickDataset, m.datasets.Dataset)
+    assert issubclass(m.models.MatrixFactorization, m.models.Model)
+    ds = m.datasets.ClickDataset(click_dataset=np.zeros((12, 2), np.uint64), historical_items=np.zeros((4, 5), np.uint64),
+                                 masks=np.ones((4, 1), np.uint64))
+    assert ds.data_rows == 12 and ds.max_his == 0
+    ds.max_his = 5
+    ds.data_rows = 12
+    with pytest.raises(ValueError):   # the reference would silently bind a converted temporary
+        m.datasets.ClickDataset(click_dataset=np.zeros((12, 2), np.int32), historical_items=np.zeros((4, 5), np.uint64),
+                                masks=np.ones((4, 1), np.uint64))
+    with pytest.raises(ValueError):
+        m.datasets.ClickDataset(click_dataset=np.zeros((12, 4), np.uint64)[:, ::2], historical_items=np.zeros((4, 5), np.uint64),
+                                masks=np.ones((4, 1), np.uint64))
+    model = m.models.MatrixFactorization(cf_config=cfg, user_weights=np.zeros((4, 64), np.float32),
+                                         item_weights=np.zeros((10, 64), np.float32))
+    with pytest.raises(ValueError):
+        m.models.MatrixFactorization(cf_config=cfg, user_weights=np.zeros((4, 32), np.float32),
+                                     item_weights=np.zeros((10, 64), np.float32))
+    agg = m.behavior_aggregators.AggregatorWeights(aggregator_weights0=np.zeros((64, 64), np.float32))
+    assert agg.emb_dim == 64
+    assert hasattr(m.train.Engine, "train_one_epoch") and hasattr(m.train.Engine, "evaluate0")
+    # no GPU in this container: constructing the engine must fail loudly, never fall back to a CPU path
+    with pytest.raises(RuntimeError, match="no usable HIP device|no CPU fallback"):
+        m.train.Engine(dataset=ds, aggregator_weights=agg, model=model, cf_config=cfg)
+
+
+def test_abi_exports_every_declared_symbol():
+    """Every function include/heat_cf.h declares is exported by lib/libheat_cf.so and typed in heat_amd.abi."""
+    from heat_amd import abi
+    hdr = open(os.path.join(ROOT, "include", "heat_cf.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(heat_cf_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(abi.SYMBOLS), declared ^ set(abi.SYMBOLS)
+    lib = abi.load()
+    for name in declared:
+        assert getattr(lib, name) is not None
+    assert lib.heat_cf_abi_version() == 1
+
+
+def test_abi_struct_layout_matches_header(tmp_path):
+    """ctypes mirror of heat_cf_config / heat_cf_device_view vs the layout gcc gives the header's structs."""
+    import ctypes as C
+    import subprocess
+    from heat_amd import abi
+    fields = [f[0] for f in abi.Config._fields_]
+    vfields = [f[0] for f in abi.DeviceView._fields_]
+    src = tmp_path / "layout.c"
+    lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{ROOT}/include/heat_cf.h"', 'int main(void){',
+             'printf("%zu\\n", sizeof(heat_cf_config));']
+    lines += [f'printf("%zu\\n", offsetof(heat_cf_config, {f}));' for f in fields]
+    lines += ['printf("%zu\\n", sizeof(heat_cf_device_view));']
+    lines += [f'printf("%zu\\n", offsetof(heat_cf_device_view, {f}));' for f in vfields]
+    lines += ['return 0;}']
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", str(src), "-o", str(exe)])
+    out = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    want = [C.sizeof(abi.Config)] + [getattr(abi.Config, f).offset for f in fields]
+    want += [C.sizeof(abi.DeviceView)] + [getattr(abi.DeviceView, f).offset for f in vfields]
+    assert out == want
+
+
+def test_lightgcn_parser(golden_dir):
+    """cf/datasets.py:31-79 semantics on a hand-made file: file order, history padding with the last item, masks."""
+    from heat_amd.cf.cf_config import CFConfig
+    from heat_amd.cf.datasets import ClickDataset
+    with contextlib.redirect_stdout(io.StringIO()):
+        cfg = CFConfig(emb_dim=64, num_negs=4, max_his=4, milestones=[10])
+        tr = ClickDataset(os.path.join(golden_dir, "tiny_lightgcn", "train.txt"), config=cfg, seed=1)
+        te = ClickDataset(os.path.join(golden_dir, "tiny_lightgcn", "test.txt"), config=cfg, seed=1)
+    assert tr.click_dataset.dtype == np.uint64
+    assert tr.click_dataset.tolist() == [[0, 3], [0, 4], [0, 7], [1, 0], [1, 1], [1, 2], [1, 3], [1, 5], [1, 6], [2, 9],
+                                         [3, 2], [3, 8]]
+    assert (cfg.num_users, cfg.num_items, cfg.train_size) == (4, 10, 12)
+    assert tr.masks[:, 0].tolist() == [3, 4, 1, 2]
+    assert tr.his_items[0].tolist() == [3, 4, 7, 7] and tr.his_items[2].tolist() == [9, 9, 9, 9]
+    assert sorted(tr.his_items[1].tolist()) == sorted(set(tr.his_items[1].tolist())) and set(tr.his_items[1]) <= {0, 1, 2, 3, 5, 6}
+    assert tr.c_instance.max_his == 4 and tr.c_instance.data_rows == 12
+    assert te.c_instance is None and te.user_items_dic == {0: [1, 2], 1: [9], 3: [0, 5]}
+    indptr, items = tr.train_csr()
+    assert indptr.tolist() == [0, 3, 9, 10, 12] and items.tolist() == [3, 4, 7, 0, 1, 2, 3, 5, 6, 9, 2, 8]
+
+
+def test_yaml_configs_carry_the_reference_keys():
+    from heat_amd.cf import utils
+    base = os.path.join(ROOT, "heat_amd", "cf", "benchmarks")
+    want = {"AmazonBooks/MF_CCL/configs/config0.yaml": (64, 16, 1.0, 5, 2), "Yelp18/MF_CCL/configs/config0.yaml": (128, 64, 0.1, 8, 10),
+            "Gowalla/MF_CCL/configs/config0.yaml": (128, 64, 0.1, 8, 10), "Gowalla/MF_CCL/configs/config_pr1.yaml": (64, 16, 1.0, 5, 2)}
+    for rel, (d, n, clip, ep, ev) in want.items():
+        c = utils.load_config(os.path.join(base, rel))["model_config"]
+        assert (c["embedding_dim"], c["num_negs"], c["clip_val"], c["epochs"], c["eval_interval"]) == (d, n, clip, ep, ev)
+        for k in ["max_his", "neg_sampler", "tile_size", "refresh_interval", "embedding_regularizer", "milestones",
+                  "learning_rate", "seed"]:
+            assert k in c
+
+
+def test_synthetic_graph_properties():
+    from heat_amd.cf import synthetic
+    g = synthetic.make_graph(500, 800, 9000, seed=3)
+    assert g.clicks.shape == (9000, 2) and g.clicks.dtype == np.uint64
+    u = g.clicks[:, 0].astype(np.int64)
+    assert (np.diff(u) >= 0).all()                                  # LightGCN order: grouped by user
+    key = g.clicks[:, 0] * np.uint64(800) + g.clicks[:, 1]
+    assert np.unique(key).size == 9000                              # no duplicate (user,item)
+    assert (np.bincount(u, minlength=500) >= 1).all()
+    g2 = synthetic.make_graph(500, 800, 9000, seed=3)
+    assert np.array_equal(g.clicks, g2.clicks) and np.array_equal(g.test_items, g2.test_items)   # seeded
+    # test items are disjoint from the user's train items
+    tp, ep = g.train_indptr.astype(np.int64), g.test_indptr.astype(np.int64)
+    for usr in range(0, 500, 37):
+        assert not set(g.train_items[tp[usr]:tp[usr + 1]].tolist()) & set(g.test_items[ep[usr]:ep[usr + 1]].tolist())
