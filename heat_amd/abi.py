@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(HERE, "lib", "libheat_cf.so")
 OK, EINVAL, EHIP, ENOMEM, EUNSUP = 0, -1, -2, -3, -4
 FLAG_SERIAL, FLAG_LAZY_SYNC, FLAG_SAMPLING_CALL = 0x1, 0x2, 0x4
 COHERENCE_DEFAULT, COHERENCE_PLAIN, COHERENCE_DEVICE = 0, 1, 2
+UPDATE_DEFAULT, UPDATE_OVERWRITE, UPDATE_ATOMIC_W, UPDATE_ATOMIC_WG = 0, 1, 2, 3
 
 
 class Config(C.Structure):
@@ -25,7 +26,7 @@ class Config(C.Structure):
                 ("n_milestones", C.c_uint64), ("l_r", C.c_float),
                 ("seed", C.c_uint64), ("sample_index_base", C.c_uint64), ("use_aggregator", C.c_uint32),
                 ("flags", C.c_uint32), ("coherence", C.c_uint32), ("device", C.c_int32),
-                ("num_streams", C.c_uint32), ("reserved", C.c_uint32)]
+                ("num_streams", C.c_uint32), ("update_mode", C.c_uint32)]
 
 
 class DeviceView(C.Structure):
@@ -106,11 +107,11 @@ def _ptr(a):
 def make_config(*, emb_dim, num_negs, num_users, num_items, train_size, neg_sampler=0, tile_size=512,
                 refresh_interval=8192, num_subepochs=2, l2=1e-7, clip_val=1.0, milestones=(10,), l_r=0.01, seed=2022,
                 sample_index_base=0, use_aggregator=False, flags=0, coherence=COHERENCE_DEFAULT, device=-1,
-                num_streams=0):
+                num_streams=0, update_mode=UPDATE_DEFAULT):
     ms = np.ascontiguousarray(np.asarray(list(milestones), dtype=np.uint64))
     cfg = Config(emb_dim, num_negs, num_users, num_items, train_size, neg_sampler, tile_size, refresh_interval,
                  num_subepochs, l2, clip_val, ms.ctypes.data_as(C.POINTER(C.c_uint64)), len(ms), l_r, seed,
-                 sample_index_base, int(use_aggregator), flags, coherence, device, num_streams, 0)
+                 sample_index_base, int(use_aggregator), flags, coherence, device, num_streams, update_mode)
     cfg._keepalive = ms
     return cfg
 

@@ -6,7 +6,7 @@ from .cpp_base import CPPBase
 class CFConfig(CPPBase):
     def __init__(self, emb_dim=64, num_negs=4, max_his=8, num_users=128, num_items=128, train_size=128,
                  neg_sampler=0, tile_size=1024, num_subepoches=2, refresh_interval=2048, l2=1.e-3, clip_val=0.1,
-                 milestones=(), l_r=1.e-3, seed=2022, use_aggregator=False, coherence=0, flags=0, num_streams=0):
+                 milestones=(), l_r=1.e-3, seed=2022, use_aggregator=False, coherence=0, flags=0, num_streams=0, update_mode=0):
         super().__init__()
         from heat_amd import cf_c  # the built pybind11 module; raises ImportError when it has not been built
         self.c_class = cf_c.modules.CFConfig
@@ -32,6 +32,7 @@ class CFConfig(CPPBase):
         self.coherence = coherence
         self.flags = flags
         self.num_streams = num_streams
+        self.update_mode = update_mode
 
     def init_c_instance(self):
         self.c_instance = self.c_class(emb_dim=self.emb_dim, num_negs=self.num_negs, num_users=self.num_users,
@@ -44,3 +45,4 @@ class CFConfig(CPPBase):
         self.c_instance.coherence = int(self.coherence)
         self.c_instance.flags = int(self.flags)
         self.c_instance.num_streams = int(self.num_streams)
+        self.c_instance.update_mode = int(self.update_mode)

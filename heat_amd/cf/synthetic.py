@@ -33,8 +33,13 @@ class Graph:
 
 
 def make_graph(num_users, num_items, train_size, seed=2022, test_frac=0.2, zipf_s=1.0, deg_alpha=1.8, min_deg=2,
-               with_test=True):
-    """Returns a Graph with exactly `train_size` train interactions (requires train_size >= num_users)."""
+               with_test=True, n_clusters=0, in_cluster=0.8):
+    """Returns a Graph with exactly `train_size` train interactions (requires train_size >= num_users).
+
+    n_clusters = 0 is the SURVEY §8d generator (popularity only: the best recommender is the popularity ranking).
+    n_clusters > 0 adds latent structure: users and items belong to clusters and a user draws `in_cluster` of its
+    items from its own cluster (skewed inside the cluster), the rest from the global Zipf; Recall/NDCG then depend on
+    the learned user/item geometry, which makes parity checks more discriminating."""
     if train_size < num_users:
         raise ValueError("train_size must be >= num_users (every user keeps at least one train item)")
     rng = np.random.default_rng(seed)
@@ -58,10 +63,26 @@ def make_graph(num_users, num_items, train_size, seed=2022, test_frac=0.2, zipf_
     def draw(n):
         return perm[np.searchsorted(cdf, rng.random(n), side="right").clip(0, num_items - 1)]
 
+    if n_clusters > 0:
+        user_cl = rng.integers(0, n_clusters, size=num_users)
+        item_cl = rng.integers(0, n_clusters, size=num_items)
+        order_c = np.argsort(item_cl, kind="stable")
+        cl_start = np.searchsorted(item_cl[order_c], np.arange(n_clusters))
+        cl_size = np.maximum(1, np.bincount(item_cl, minlength=n_clusters))
+
+    def draw_for(users_arr):
+        out = draw(users_arr.size).astype(np.int64)
+        if n_clusters > 0:
+            inc = rng.random(users_arr.size) < in_cluster
+            c = user_cl[users_arr[inc]]
+            r = np.floor(cl_size[c] * rng.random(c.size) ** 2).astype(np.int64).clip(0, cl_size[c] - 1)
+            out[inc] = order_c[(cl_start[c] + r).clip(0, num_items - 1)]
+        return out
+
     # oversample, dedup (user,item), keep up to deg[u] per user
-    over = 1.35
+    over = 1.35 if n_clusters == 0 else 1.8
     users = np.repeat(np.arange(num_users, dtype=np.int64), np.ceil(deg * over).astype(np.int64) + 2)
-    items = draw(users.size).astype(np.int64)
+    items = draw_for(users)
     key = np.unique(users * num_items + items)
     users, items = key // num_items, key % num_items
     # shuffle within user so that the kept subset / split is not item-id ordered
@@ -132,7 +153,7 @@ def make_graph(num_users, num_items, train_size, seed=2022, test_frac=0.2, zipf_
     return Graph(num_users, num_items, np.ascontiguousarray(clicks), train_indptr, test_indptr, te_i.astype(np.uint32))
 
 
-def make_named(name, seed=2022, scale=1.0, **kw):
+def make_named(name, seed=2022, scale=1.0, **kw):  # kw: with_test, n_clusters, in_cluster, ...
     """Graph of a named shape; `scale` < 1 shrinks users/items/interactions together (parity-test sizes)."""
     U, I, T, d, N = SHAPES[name]
     U, I, T = max(8, int(U * scale)), max(64, int(I * scale)), max(8, int(T * scale))

@@ -27,9 +27,85 @@
 namespace heatcf
 {
 
+// Stream boundaries follow user runs: a stream owns every run that STARTS inside its nominal slice, so one user's
+// interactions are never split between two concurrently running waves (each would keep the user row in registers and
+// overwrite the other's updates).  x is moved forward to the next run start, looking at most `cap` entries ahead; a
+// run longer than that is split at x.  Both neighbours evaluate the same function, so slices stay disjoint.
+__device__ __forceinline__ uint64_t align_to_user_run(const uint2* clicks, uint64_t x, uint64_t begin, uint64_t end,
+                                                      uint32_t cap, int lane)
+{
+    if (x >= end) return end;
+    if (x <= begin) return begin;
+    const uint32_t prev_user = clicks[x - 1].x;
+    for (uint32_t off = 0; off < cap; off += 64)
+    {
+        const uint64_t i = x + off + (uint64_t)lane;
+        const bool differs = (i >= end) || (clicks[i].x != prev_user);
+        const uint64_t m = __builtin_amdgcn_ballot_w64(differs);
+        if (m != 0ull) return x + off + (uint64_t)__builtin_ctzll(m);
+    }
+    return x;
+}
+
+// Float atomic adds run at full rate only when one wave instruction covers 256 contiguous bytes (one dword per lane);
+// the row layout of this kernel is 16 B per lane, so a component-wise atomic would touch 4 dwords of every 64-B
+// segment (4x the memory-side atomic requests per byte: measured 0.31 TB/s vs ~1.3 TB/s).  The deltas of one register
+// group (64 lanes x 16 B = 1 KiB = R rows) are therefore transposed through a wave-private 1 KiB LDS tile: lane l of
+// chunk q adds dword l of bytes [256q, 256q+256) of the tile, whose owner in the row layout is lane 16q + l/4.
+struct AtomicOffsets
+{
+    uint32_t o[4];
+};
+
+__device__ __forceinline__ AtomicOffsets atomic_offsets(uint32_t off, int lane)
+{
+    AtomicOffsets a;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) a.o[q] = lane_get(off, 16 * q + (lane >> 2)) + 4u * (uint32_t)(lane & 3); // OOB stays OOB
+    return a;
+}
+
+template <int NCHUNK>
+__device__ __forceinline__ void atomic_add_tile(__amdgpu_buffer_rsrc_t rsrc, const AtomicOffsets& ao, f32x4 delta,
+                                                float* tile, int lane)
+{
+    *reinterpret_cast<f32x4*>(tile + lane * 4) = delta;
+#pragma unroll
+    for (int q = 0; q < NCHUNK; ++q)
+        __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(tile[q * 64 + lane], rsrc, (int)ao.o[q], 0, 0);
+}
+
+template <int LPR, int AUX>
+__device__ __forceinline__ void flush_user_row(const TrainArgs& a, uint32_t user, bool cut, f32x4 u4, f32x4 gu4, f32x4 u4_in,
+                                               f32x4 gu4_in, float* tile, int lane, int rr, bool col_ok, uint32_t col_off)
+{
+    const size_t o = (size_t)user * a.row_bytes;
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc((const char*)a.user_w + o, a.row_bytes);
+    const __amdgpu_buffer_rsrc_t rg = make_rsrc((const char*)a.user_g + o, a.row_bytes);
+    const uint32_t off = (rr == 0 && col_ok) ? col_off : OOB_OFF;
+    if (cut)
+    {
+        constexpr int NCH = LPR >= 16 ? LPR / 16 : 1;
+        const AtomicOffsets ao = atomic_offsets(off, lane);
+        atomic_add_tile<NCH>(rw, ao, u4 - u4_in, tile, lane);
+        atomic_add_tile<NCH>(rg, ao, gu4 - gu4_in, tile, lane);
+    }
+    else
+    {
+        buf_store<AUX>(rw, off, u4);
+        buf_store<AUX>(rg, off, gu4);
+    }
+}
+
+// a.upd_bits selects, per kind of row, how the update is written back (wave-uniform branches):
+//   bit 0: negative W by atomic add   bit 1: negative G by atomic add
+//   bit 2: positive W by atomic add   bit 3: positive G by atomic add      (0 = the reference's literal overwrite)
 template <int LPR, int NG, int AUX>
 __global__ __launch_bounds__(64) void ccl_train_kernel(TrainArgs a)
 {
+    const bool neg_w_atomic = (a.upd_bits & 1u) != 0u, neg_g_atomic = (a.upd_bits & 2u) != 0u;
+    const bool pos_w_atomic = (a.upd_bits & 4u) != 0u, pos_g_atomic = (a.upd_bits & 8u) != 0u;
+    const bool any_atomic = a.upd_bits != 0u;
     constexpr int R = 64 / LPR;          // rows fetched by one wave instruction
     constexpr int NCAP = NG * R;         // negative slots held in registers
     constexpr int NIDV = (NCAP + 63) / 64;
@@ -46,12 +122,27 @@ __global__ __launch_bounds__(64) void ccl_train_kernel(TrainArgs a)
     const __amdgpu_buffer_rsrc_t item_w = make_rsrc(a.item_w, a.item_bytes);
     const __amdgpu_buffer_rsrc_t item_g = make_rsrc(a.item_g, a.item_bytes);
 
-    const uint64_t first = a.begin + (uint64_t)blockIdx.x * a.per_block;
+    uint64_t first = a.begin + (uint64_t)blockIdx.x * a.per_block;
     uint64_t last = first + a.per_block;
     if (last > a.end) last = a.end;
+    if (a.align_cap != 0u)
+    {
+        first = align_to_user_run(a.clicks, first, a.begin, a.end, a.align_cap, lane);
+        last = align_to_user_run(a.clicks, last, a.begin, a.end, a.align_cap, lane);
+    }
+    __shared__ __attribute__((aligned(16))) float tile[256]; // one wave per workgroup: wave-private transpose tile
+    // A user run cut by a stream boundary is also being updated by the neighbouring stream: its row is then written
+    // back as an atomic delta (nothing lost); a run owned entirely by this stream is written back with plain stores.
+    uint32_t cut_head_user = 0xFFFFFFFFu, cut_tail_user = 0xFFFFFFFFu;
+    if (any_atomic && first < last)
+    {
+        if (first > a.begin && a.clicks[first - 1].x == a.clicks[first].x) cut_head_user = a.clicks[first].x;
+        if (last < a.end && a.clicks[last].x == a.clicks[last - 1].x) cut_tail_user = a.clicks[last - 1].x;
+    }
 
     uint32_t cur_user = 0xFFFFFFFFu;
     f32x4 u4 = {0, 0, 0, 0}, gu4 = {0, 0, 0, 0};
+    f32x4 u4_in = {0, 0, 0, 0}, gu4_in = {0, 0, 0, 0};
     uint32_t nid[NIDV];
 #pragma unroll
     for (int v = 0; v < NIDV; ++v) nid[v] = 0u; // engine.cpp:298: neg_ids zero-initialised per worker
@@ -94,17 +185,16 @@ __global__ __launch_bounds__(64) void ccl_train_kernel(TrainArgs a)
             // ---- user row: registers while the user does not change (write back on change) -----------------
             if (user != cur_user)
             {
-                if (cur_user != 0xFFFFFFFFu && rr == 0 && col_ok)
-                {
-                    const size_t o = (size_t)cur_user * a.row_bytes;
-                    buf_store<AUX>(make_rsrc((const char*)a.user_w + o, a.row_bytes), col_off, u4);
-                    buf_store<AUX>(make_rsrc((const char*)a.user_g + o, a.row_bytes), col_off, gu4);
-                }
+                if (cur_user != 0xFFFFFFFFu)
+                    flush_user_row<LPR, AUX>(a, cur_user, cur_user == cut_head_user || cur_user == cut_tail_user, u4, gu4,
+                                             u4_in, gu4_in, tile, lane, rr, col_ok, col_off);
                 cur_user = user;
                 const size_t o = (size_t)user * a.row_bytes;
                 const uint32_t uo = col_ok ? col_off : OOB_OFF;
                 u4 = buf_load<AUX>(make_rsrc((const char*)a.user_w + o, a.row_bytes), uo);
                 gu4 = buf_load<AUX>(make_rsrc((const char*)a.user_g + o, a.row_bytes), uo);
+                u4_in = u4;
+                gu4_in = gu4;
             }
 
             // ---- gather: positive row (replicated in every row group) + N negative rows, W and G -----------
@@ -136,9 +226,9 @@ __global__ __launch_bounds__(64) void ccl_train_kernel(TrainArgs a)
             uint32_t cmul[NG];
             uint32_t cmax = 1u;
             {
-                uint32_t eq[NIDV];
+                uint32_t eq[NIDV], earlier[NIDV];
 #pragma unroll
-                for (int v = 0; v < NIDV; ++v) eq[v] = 0u;
+                for (int v = 0; v < NIDV; ++v) { eq[v] = 0u; earlier[v] = 0u; }
                 for (uint32_t s = 0; s < N; ++s)
                 {
                     uint32_t sid = 0u;
@@ -146,7 +236,12 @@ __global__ __launch_bounds__(64) void ccl_train_kernel(TrainArgs a)
                     for (int v = 0; v < NIDV; ++v)
                         if ((int)(s >> 6) == v) sid = (uint32_t)__builtin_amdgcn_readlane((int)nid[v], (int)(s & 63u));
 #pragma unroll
-                    for (int v = 0; v < NIDV; ++v) eq[v] += (nid[v] == sid && (uint32_t)(v * 64 + lane) < N) ? 1u : 0u;
+                    for (int v = 0; v < NIDV; ++v)
+                    {
+                        const bool same = nid[v] == sid && (uint32_t)(v * 64 + lane) < N;
+                        eq[v] += same ? 1u : 0u;
+                        earlier[v] += (same && s < (uint32_t)(v * 64 + lane)) ? 1u : 0u;
+                    }
                 }
                 bool any_dup = false;
 #pragma unroll
@@ -158,6 +253,9 @@ __global__ __launch_bounds__(64) void ccl_train_kernel(TrainArgs a)
                     {
                         cmul[g] = valid[g] ? lane_get(eq[(g * R) / 64], (g * R + rr) & 63) : 1u;
                         cmax = cmul[g] > cmax ? cmul[g] : cmax;
+                        // with atomic W updates only the first copy of a duplicated row adds its (c-fold) delta: the
+                        // reference's copies all write the same W_stale - lr*G_c (last writer wins, one effective update)
+                        if (neg_w_atomic && lane_get(earlier[(g * R) / 64], (g * R + rr) & 63) != 0u) noff[g] = OOB_OFF;
                     }
                     // wave-uniform upper bound
 #pragma unroll
@@ -238,9 +336,19 @@ __global__ __launch_bounds__(64) void ccl_train_kernel(TrainArgs a)
                     const f32x4 g2 = clip4(gn + t, clip);
                     if (c < cmul[g]) gn = g2;
                 }
-                const f32x4 nw = n4[g] - lr * gn;                               // sgd.cpp:23
-                buf_store<AUX>(item_w, noff[g], nw);                            // :148
-                buf_store<AUX>(item_g, noff[g], gn);                            // :149
+                if (!neg_w_atomic && !neg_g_atomic)
+                {
+                    buf_store<AUX>(item_w, noff[g], n4[g] - lr * gn);           // sgd.cpp:23, :148
+                    buf_store<AUX>(item_g, noff[g], gn);                        // :149
+                }
+                else
+                {
+                    const AtomicOffsets ao = atomic_offsets(noff[g], lane);
+                    if (neg_w_atomic) atomic_add_tile<4>(item_w, ao, -(lr * gn), tile, lane); // W += -(lr*G)
+                    else buf_store<AUX>(item_w, noff[g], n4[g] - lr * gn);
+                    if (neg_g_atomic) atomic_add_tile<4>(item_g, ao, gn - gn4[g], tile, lane);
+                    else buf_store<AUX>(item_g, noff[g], gn);
+                }
             }
             gu_acc.x = cross_sum<LPR>(gu_acc.x);
             gu_acc.y = cross_sum<LPR>(gu_acc.y);
@@ -250,20 +358,29 @@ __global__ __launch_bounds__(64) void ccl_train_kernel(TrainArgs a)
 
             gu4 = clip4(gu4 + gu_acc, clip);                                    // :166
             u4 = u4 - lr * gu4;
+            const f32x4 gp_old = gp4;
             gp4 = clip4(gp4 + slg * upp, clip);                                 // :169
-            p4 = p4 - lr * gp4;
             const uint32_t pst = (rr == 0 && col_ok) ? pos * a.row_bytes + col_off : OOB_OFF;
-            buf_store<AUX>(item_w, pst, p4);                                    // :173
-            buf_store<AUX>(item_g, pst, gp4);                                   // :174
+            if (!pos_w_atomic && !pos_g_atomic)
+            {
+                buf_store<AUX>(item_w, pst, p4 - lr * gp4);                     // :173
+                buf_store<AUX>(item_g, pst, gp4);                               // :174
+            }
+            else
+            {
+                constexpr int NCH = LPR >= 16 ? LPR / 16 : 1;                   // row 0 of the tile only
+                const AtomicOffsets ao = atomic_offsets(pst, lane);
+                if (pos_w_atomic) atomic_add_tile<NCH>(item_w, ao, -(lr * gp4), tile, lane);
+                else buf_store<AUX>(item_w, pst, p4 - lr * gp4);
+                if (pos_g_atomic) atomic_add_tile<NCH>(item_g, ao, gp4 - gp_old, tile, lane);
+                else buf_store<AUX>(item_g, pst, gp4);
+            }
         }
     }
 
-    if (cur_user != 0xFFFFFFFFu && rr == 0 && col_ok)
-    {
-        const size_t o = (size_t)cur_user * a.row_bytes;
-        buf_store<AUX>(make_rsrc((const char*)a.user_w + o, a.row_bytes), col_off, u4);   // :171
-        buf_store<AUX>(make_rsrc((const char*)a.user_g + o, a.row_bytes), col_off, gu4);  // :172
-    }
+    if (cur_user != 0xFFFFFFFFu)                                                           // :171-172
+        flush_user_row<LPR, AUX>(a, cur_user, cur_user == cut_head_user || cur_user == cut_tail_user, u4, gu4, u4_in,
+                                 gu4_in, tile, lane, rr, col_ok, col_off);
     if (lane == 0) a.loss_part[blockIdx.x] = loss_acc;
 }
 
@@ -303,9 +420,11 @@ __global__ __launch_bounds__(64) void sample_negs_kernel(TrainArgs a, uint64_t o
 {
     const int lane = (int)threadIdx.x;
     const uint32_t N = a.num_negs;
-    const uint64_t first = a.begin + (uint64_t)blockIdx.x * a.per_block;
+    uint64_t first = a.begin + (uint64_t)blockIdx.x * a.per_block;
     uint64_t last = first + a.per_block;
     if (last > a.end) last = a.end;
+    first = align_to_user_run(a.clicks, first, a.begin, a.end, a.align_cap, lane);
+    last = align_to_user_run(a.clicks, last, a.begin, a.end, a.align_cap, lane);
     const int nidv = (int)((N + 63u) / 64u);
     uint32_t prev[4] = {0u, 0u, 0u, 0u};
     for (uint64_t idx = first; idx < last; ++idx)
@@ -334,7 +453,7 @@ static hipError_t launch_variant(const TrainArgs& a, uint32_t grid, int aux, hip
 }
 
 #define HEATCF_VARIANTS(X) \
-    X(8, 1) X(8, 2) X(8, 4) X(8, 8) \
+    X(8, 1) X(8, 2) X(8, 4) \
     X(16, 2) X(16, 4) X(16, 8) X(16, 16) X(16, 25) \
     X(32, 4) X(32, 8) X(32, 16) X(32, 32) \
     X(64, 8) X(64, 16) X(64, 32)

@@ -19,6 +19,8 @@ struct TrainArgs
     uint32_t     num_items, num_negs, emb_dim, row_bytes;
     uint32_t     item_bytes; // num_items * row_bytes (< 4 GiB: 32-bit buffer offsets)
     uint32_t     sampling_call;
+    uint32_t     upd_bits;   // bit0 neg W atomic, bit1 neg G atomic, bit2 pos W atomic, bit3 pos G atomic
+    uint32_t     align_cap;  // how far a stream boundary may move forward to the next user-run start
     float        lr, clip;
     uint64_t     key;         // Philox key for this epoch
     uint64_t     sample_base; // added to the interaction index in the Philox counter

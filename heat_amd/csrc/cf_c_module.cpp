@@ -72,6 +72,7 @@ struct CFConfig
         flags = (uint32_t)env_u64("HEAT_CF_FLAGS", 0);
         coherence = (uint32_t)env_u64("HEAT_CF_COHERENCE", 0);
         num_streams = (uint32_t)env_u64("HEAT_CF_NUM_STREAMS", 0);
+        update_mode = (uint32_t)env_u64("HEAT_CF_UPDATE_MODE", 0);
         device = -1;
         sample_index_base = 0;
     }
@@ -81,7 +82,7 @@ struct CFConfig
     val_t l_r;
     // extensions
     uint64_t seed, sample_index_base;
-    uint32_t use_aggregator, flags, coherence, num_streams;
+    uint32_t use_aggregator, flags, coherence, num_streams, update_mode;
     int32_t  device;
 };
 
@@ -183,6 +184,7 @@ struct Engine
         hc.coherence = c->coherence;
         hc.device = c->device;
         hc.num_streams = c->num_streams;
+        hc.update_mode = c->update_mode;
         // engine.cpp:79 iterates train_data->data_rows (a Python-settable attribute, init_modules.cpp:60)
         const idx_t rows = std::min<idx_t>(ds->data_rows, (idx_t)ds->click_dataset.shape(0));
         check(heat_cf_engine_create(&hc, static_cast<const uint64_t*>(ds->click_dataset.data()), rows,
@@ -282,6 +284,7 @@ PYBIND11_MODULE(cf_c, cf_module)
         .def_readwrite("flags", &CFConfig::flags)
         .def_readwrite("coherence", &CFConfig::coherence)
         .def_readwrite("num_streams", &CFConfig::num_streams)
+        .def_readwrite("update_mode", &CFConfig::update_mode)
         .def_readwrite("device", &CFConfig::device);
 
     py::module_ datasets = modules.def_submodule("datasets", "datasets");

@@ -76,7 +76,7 @@ struct heat_cf_engine
     float    lr = 0.f;
     uint64_t epoch = 0;
     // kernel choice
-    int      lpr = 0, ng = 0, aux = 0;
+    int      lpr = 0, ng = 0, aux = 0, upd = 0;
     uint32_t cu_count = 256;
     char     kname[96] = {0};
     // timing
@@ -153,6 +153,17 @@ int common_init(heat_cf_engine* e, const heat_cf_config* cfg, uint64_t data_rows
     const uint32_t coh = cfg->coherence == HEAT_CF_COHERENCE_DEFAULT ? HEAT_CF_COHERENCE_DEVICE : cfg->coherence;
     if (coh != HEAT_CF_COHERENCE_PLAIN && coh != HEAT_CF_COHERENCE_DEVICE) return fail(HEAT_CF_EINVAL, "bad coherence");
     e->aux = coh == HEAT_CF_COHERENCE_DEVICE ? 16 : 0;
+    uint32_t um = cfg->update_mode;
+    if (um == HEAT_CF_UPDATE_DEFAULT) um = coh == HEAT_CF_COHERENCE_DEVICE ? HEAT_CF_UPDATE_ATOMIC_WG : HEAT_CF_UPDATE_OVERWRITE;
+    uint32_t bits;
+    if (um == HEAT_CF_UPDATE_OVERWRITE) bits = 0u;
+    else if (um == HEAT_CF_UPDATE_ATOMIC_W) bits = 0x5u;
+    else if (um == HEAT_CF_UPDATE_ATOMIC_WG) bits = 0xFu;
+    else if (um >= 16u && um < 32u) bits = um - 16u; // experimental: raw bit mask (bit0 neg W, bit1 neg G, bit2 pos W, bit3 pos G)
+    else return fail(HEAT_CF_EINVAL, "bad update_mode");
+    if (bits != 0u && coh != HEAT_CF_COHERENCE_DEVICE)
+        return fail(HEAT_CF_EINVAL, "atomic update modes need HEAT_CF_COHERENCE_DEVICE");
+    e->upd = (int)bits;
     std::snprintf(e->kname, sizeof(e->kname), "ccl_train_kernel<%d,%d,%d>", e->lpr, e->ng, e->aux);
     HIP_TRY(hipMalloc(&e->d_sums, 2 * sizeof(double)));
     HIP_TRY(hipMemsetAsync(e->d_sums, 0, 2 * sizeof(double), e->stream));
@@ -233,6 +244,8 @@ TrainArgs make_args(const heat_cf_engine* e, uint64_t begin, uint64_t end)
     a.row_bytes = (uint32_t)e->cfg.emb_dim * 4u;
     a.item_bytes = (uint32_t)(e->cfg.num_items * e->cfg.emb_dim * 4ull);
     a.sampling_call = (e->cfg.flags & HEAT_CF_FLAG_SAMPLING_CALL) ? 1u : 0u;
+    a.upd_bits = (uint32_t)e->upd;
+    a.align_cap = e->upd == 0 ? 4096u : 0u; // overwrite mode keeps a user's run inside one stream; atomic modes need not
     a.lr = e->lr;
     a.clip = e->cfg.clip_val;
     a.key = epoch_key(e->cfg.seed, e->epoch);

@@ -50,6 +50,13 @@ extern "C" {
 #define HEAT_CF_COHERENCE_PLAIN   1 /* plain loads/stores: per-XCD L2 copies may diverge inside one launch      */
 #define HEAT_CF_COHERENCE_DEVICE  2 /* sc1 loads + sc1 write-through stores: coherent across the 8 XCDs         */
 
+/* how an item row's (W, G) update is written back (see DESIGN.md "Hogwild at GPU concurrency") */
+#define HEAT_CF_UPDATE_DEFAULT   0 /* engine picks (ATOMIC_WG when device-coherent)                                  */
+#define HEAT_CF_UPDATE_OVERWRITE 1 /* W <- W_read - lr*G, plain stores: the reference's literal memcpy write-back;
+                                      concurrent streams touching one row lose updates (last writer wins)          */
+#define HEAT_CF_UPDATE_ATOMIC_W  2 /* W += -lr*G by float atomic add (no update lost), G by plain store            */
+#define HEAT_CF_UPDATE_ATOMIC_WG 3 /* W as above, G += (G_new - G_read) by float atomic add                        */
+
 /* Replaces cf::modules::CFConfig (modules/cf_config.hpp:12-35; bound at pybind/init_modules.cpp:13-33).
  * The first 13 fields are the reference's, in its constructor order.  The rest are extensions the
  * reference does not have (it ignores yaml `seed`, main.py:19-124). */
@@ -77,7 +84,7 @@ typedef struct heat_cf_config
     uint32_t coherence;         /* HEAT_CF_COHERENCE_* */
     int32_t  device;            /* HIP device ordinal; -1 = current device */
     uint32_t num_streams;       /* concurrent sequential interaction streams (waves); 0 = auto */
-    uint32_t reserved;
+    uint32_t update_mode;       /* HEAT_CF_UPDATE_* */
 } heat_cf_config;
 
 typedef struct heat_cf_engine heat_cf_engine;

@@ -157,19 +157,50 @@ def test_epoch_protocol_lr_schedule_zero_grad_and_inplace_weights():
     eng.close()
 
 
-def test_parallel_epoch_statistically_matches_oracle_epoch():
-    """Hogwild GPU epoch (thousands of streams, on-GPU sampler) vs oracle epoch (1 thread, mt19937_64 sampler):
-    different negatives and interleavings, so the comparison is statistical: mean loss within 2 %."""
-    d, N = 64, 16
-    g, _, _ = synthetic.make_named("gowalla", scale=0.05)
-    uw, iw = synthetic.init_embeddings(g.num_users, g.num_items, d)
+def test_recall_ndcg_parity_amazonbooks_shape():
+    """The north-star parity criterion: Recall@20 / NDCG@20 of the Hogwild GPU engine (thousands of concurrent
+    streams, on-GPU Philox negatives) vs the CPU oracle (8 OpenMP threads, mt19937_64 negatives) within +-1e-3 after the
+    yaml's 5 epochs, same synthetic AmazonBooks-shaped graph, same N(0,0.01^2) tables, seed 2022.  The two runs draw
+    different negatives and interleave differently, so this is a statistical comparison; epoch losses within 4 %."""
+    import types
+    from heat_amd.cf import metrics
+    g, d, N = synthetic.make_named("amazonbooks")
+    uw, iw = synthetic.init_embeddings(g.num_users, g.num_items, d, seed=2022)
     uo, io = uw.copy(), iw.copy()
-    eng = abi.Engine(g.clicks, uw, iw, num_negs=N, seed=2022)
+    eng = abi.Engine(g.clicks, uw, iw, num_negs=N, seed=2022, flags=abi.FLAG_LAZY_SYNC)
     ora = orc.Engine(g.clicks, uo, io, num_negs=N)
-    for _ in range(3):
-        lg, lo = eng.train_one_epoch(), ora.train_one_epoch(num_threads=1)
-        assert abs(lg - lo) <= 0.02 * lo, (lg, lo)
-    eng.close()
+    lg = [eng.train_one_epoch() for _ in range(5)]
+    lo = [ora.train_one_epoch(num_threads=8) for _ in range(5)]
+    eng.sync_to_host()
+    for a, b in zip(lg, lo):
+        assert abs(a - b) <= 0.04 * b, (lg, lo)
+    ep = g.test_indptr.astype(np.int64)
+    test = types.SimpleNamespace(user_items_dic={u: g.test_items[ep[u]:ep[u + 1]].tolist()
+                                                 for u in range(g.num_users) if ep[u + 1] > ep[u]})
+    ms = ["Recall(k=20)", "NDCG(k=20)"]
+    top_g = eng.topk(20, mask_indptr=g.train_indptr, mask_items=g.train_items)
+    ev = abi.Engine(g.clicks[:1].copy(), uo, io, num_negs=N)     # the oracle's tables, ranked by the same top-k kernel
+    top_o = ev.topk(20, mask_indptr=g.train_indptr, mask_items=g.train_items)
+    rg = metrics.evaluate_topk(test, top_g, ms, quiet=True, by_user_id=True)
+    ro = metrics.evaluate_topk(test, top_o, ms, quiet=True, by_user_id=True)
+    print("gpu", lg, rg, "oracle", lo, ro)
+    assert ro[ms[0]] > 0.05                                       # the model learned something
+    assert abs(rg[ms[0]] - ro[ms[0]]) <= 1e-3, (rg, ro)
+    assert abs(rg[ms[1]] - ro[ms[1]]) <= 1e-3, (rg, ro)
+    eng.close(); ev.close()
+
+
+def test_overwrite_mode_loses_updates_at_gpu_concurrency():
+    """Documents WHY the default is the atomic write-back: the reference's literal overwrite, run with thousands of
+    concurrent streams, drops a large share of the updates of popular rows and the epoch loss stays visibly higher."""
+    g, d, N = synthetic.make_named("gowalla", scale=0.5)
+    losses = {}
+    for mode in (abi.UPDATE_OVERWRITE, abi.UPDATE_ATOMIC_WG):
+        uw, iw = synthetic.init_embeddings(g.num_users, g.num_items, d, seed=1)
+        eng = abi.Engine(g.clicks, uw, iw, num_negs=N, seed=1, update_mode=mode, flags=abi.FLAG_LAZY_SYNC)
+        losses[mode] = [eng.train_one_epoch() for _ in range(3)]
+        eng.close()
+    assert losses[abi.UPDATE_ATOMIC_WG][-1] < losses[abi.UPDATE_OVERWRITE][-1]
 
 
 def test_evaluate0_and_topk():

@@ -15,7 +15,8 @@ ap.add_argument("--shape", default="amazonbooks")
 ap.add_argument("--scale", type=float, default=1.0)
 ap.add_argument("--epochs", type=int, default=5)
 ap.add_argument("--streams", type=str, default="0")
-ap.add_argument("--coherence", type=str, default="1,2")
+ap.add_argument("--coherence", type=str, default="2")
+ap.add_argument("--update", type=str, default="0")
 ap.add_argument("--d", type=int, default=0)
 ap.add_argument("--negs", type=int, default=0)
 args = ap.parse_args()
@@ -25,10 +26,11 @@ d = args.d or d
 N = args.negs or N
 B = 16 * d * (N + 2) + 16
 print(f"shape={args.shape} users={g.num_users} items={g.num_items} n={g.clicks.shape[0]} d={d} N={N} B/sample={B}", flush=True)
-for coh in [int(x) for x in args.coherence.split(",")]:
+for coh, upd in [(int(c), int(u)) for c in args.coherence.split(",") for u in args.update.split(",")]:
     for streams in [int(x) for x in args.streams.split(",")]:
         uw, iw = synthetic.init_embeddings(g.num_users, g.num_items, d)
-        eng = abi.Engine(g.clicks, uw, iw, num_negs=N, coherence=coh, num_streams=streams, flags=abi.FLAG_LAZY_SYNC)
+        eng = abi.Engine(g.clicks, uw, iw, num_negs=N, coherence=coh, num_streams=streams, flags=abi.FLAG_LAZY_SYNC,
+                         update_mode=upd)
         losses = []
         eng.train_one_epoch()  # warm-up
         eng.kernel_time(reset=True)

@@ -1,0 +1,74 @@
+"""Development aid / evidence for DESIGN.md: Recall@20 / NDCG@20 of the Hogwild GPU engine vs the CPU oracle on the
+same synthetic graph and the same initial tables (run on the GPU box)."""
+import argparse
+import os
+import sys
+import time
+import types
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from heat_amd import abi
+from heat_amd.cf import metrics, synthetic
+from oracle import cf_oracle as orc
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--shape", default="amazonbooks")
+ap.add_argument("--scale", type=float, default=1.0)
+ap.add_argument("--epochs", type=int, default=5)
+ap.add_argument("--streams", type=str, default="0")
+ap.add_argument("--coherence", type=str, default="2")
+ap.add_argument("--update", type=str, default="0")
+ap.add_argument("--oracle-threads", type=str, default="8")
+ap.add_argument("--clip", type=float, default=1.0)
+ap.add_argument("--seeds", type=str, default="2022")
+ap.add_argument("--clusters", type=int, default=0)
+ap.add_argument("--lr", type=float, default=0.01)
+args = ap.parse_args()
+
+g, d, N = synthetic.make_named(args.shape, scale=args.scale, n_clusters=args.clusters)
+test_dic = {}
+ep = g.test_indptr.astype(np.int64)
+for u in range(g.num_users):
+    if ep[u + 1] > ep[u]:
+        test_dic[u] = g.test_items[ep[u]:ep[u + 1]].tolist()
+test_data = types.SimpleNamespace(user_items_dic=test_dic)
+mask_items = g.train_items
+ms = ["Recall(k=20)", "NDCG(k=20)"]
+print(f"shape={args.shape} scale={args.scale} users={g.num_users} items={g.num_items} train={g.clicks.shape[0]} "
+      f"test={g.test_items.size} d={d} N={N} epochs={args.epochs}", flush=True)
+
+
+def evaluate(uw, iw, tag):
+    e = abi.Engine(g.clicks[:1].copy(), uw, iw, num_negs=N)
+    top = e.topk(20, mask_indptr=g.train_indptr, mask_items=mask_items)
+    e.close()
+    r = metrics.evaluate_topk(test_data, top, ms, quiet=True, by_user_id=True)
+    print(f"  [{tag}] Recall@20={r[ms[0]]:.5f} NDCG@20={r[ms[1]]:.5f}", flush=True)
+    return r
+
+
+for seed in [int(x) for x in args.seeds.split(",")]:
+    uw0, iw0 = synthetic.init_embeddings(g.num_users, g.num_items, d, seed=seed)
+    for coh, upd in [(int(c), int(u)) for c in args.coherence.split(",") for u in args.update.split(",")]:
+        for streams in [int(x) for x in args.streams.split(",")]:
+            uw, iw = uw0.copy(), iw0.copy()
+            eng = abi.Engine(g.clicks, uw, iw, num_negs=N, seed=seed, coherence=coh, num_streams=streams, clip_val=args.clip, l_r=args.lr,
+                             flags=abi.FLAG_LAZY_SYNC, update_mode=upd)
+            t0 = time.time()
+            losses = [eng.train_one_epoch() for _ in range(args.epochs)]
+            dt = time.time() - t0
+            eng.sync_to_host()
+            eng.close()
+            print(f"GPU seed={seed} coherence={coh} update={upd} {eng.kernel_name if False else ''} streams={streams}: losses={[round(x, 4) for x in losses]} ({dt:.2f}s)", flush=True)
+            evaluate(uw, iw, f"gpu coh={coh} upd={upd} streams={streams}")
+    for th in [int(x) for x in args.oracle_threads.split(",")]:
+        uo, io = uw0.copy(), iw0.copy()
+        ora = orc.Engine(g.clicks, uo, io, num_negs=N, clip_val=args.clip, l_r=args.lr)
+        t0 = time.time()
+        losses = [ora.train_one_epoch(num_threads=th) for _ in range(args.epochs)]
+        dt = time.time() - t0
+        print(f"ORACLE seed={seed} threads={th}: losses={[round(x, 4) for x in losses]} ({dt:.1f}s, "
+              f"{g.clicks.shape[0] * args.epochs / dt / 1e3:.1f} k samples/s)", flush=True)
+        evaluate(uo, io, f"oracle threads={th}")
