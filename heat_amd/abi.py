@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(HERE, "lib", "libheat_cf.so")
 OK, EINVAL, EHIP, ENOMEM, EUNSUP = 0, -1, -2, -3, -4
 FLAG_SERIAL, FLAG_LAZY_SYNC, FLAG_SAMPLING_CALL = 0x1, 0x2, 0x4
 COHERENCE_DEFAULT, COHERENCE_PLAIN, COHERENCE_DEVICE = 0, 1, 2
-UPDATE_DEFAULT, UPDATE_OVERWRITE, UPDATE_ATOMIC_W, UPDATE_ATOMIC_WG = 0, 1, 2, 3
+UPDATE_DEFAULT, UPDATE_OVERWRITE, UPDATE_ATOMIC_W, UPDATE_ATOMIC_WG, UPDATE_ATOMIC_POS, UPDATE_AUTO = 0, 1, 2, 3, 4, 5
 
 
 class Config(C.Structure):
@@ -122,7 +122,25 @@ def _require(a, dtype, ndim, name):
 
 
 class Engine:
-    """Host-mode engine: numpy buffers are borrowed and trained in place (like the reference's pybind layer)."""
+    """Host-mode engine: numpy buffers are borrowed and trained in place (like the reference's pybind layer).
+    Engine.from_device(...) builds the device-mode twin on caller-owned device memory (e.g. torch tensors)."""
+
+    @classmethod
+    def from_device(cls, clicks_ptr, data_rows, user_w_ptr, item_w_ptr, *, num_users, num_items, emb_dim, num_negs,
+                    stream=None, keep=None, **cfg_kwargs):
+        """Device pointers (ints): clicks [data_rows,2] u64, user_w [num_users,emb_dim] f32, item_w [num_items,emb_dim]
+        f32, all owned by the caller; `stream` is a hipStream_t handle (int) or None; `keep` holds references alive."""
+        self = cls.__new__(cls)
+        self._keep = keep
+        self.num_negs = num_negs
+        self.data_rows = data_rows
+        self.cfg = make_config(emb_dim=emb_dim, num_negs=num_negs, num_users=num_users, num_items=num_items,
+                               train_size=data_rows, **cfg_kwargs)
+        self._h = C.c_void_p()
+        _check(load().heat_cf_engine_create_device(C.byref(self.cfg), C.c_void_p(clicks_ptr), data_rows, None, 0, None,
+                                                   C.c_void_p(user_w_ptr), C.c_void_p(item_w_ptr), None,
+                                                   C.c_void_p(stream) if stream else None, C.byref(self._h)))
+        return self
 
     def __init__(self, clicks, user_w, item_w, *, num_negs, his=None, masks=None, w0=None, **cfg_kwargs):
         _require(clicks, np.uint64, 2, "clicks")

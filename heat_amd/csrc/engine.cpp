@@ -78,6 +78,7 @@ struct heat_cf_engine
     // kernel choice
     int      lpr = 0, ng = 0, aux = 0, upd = 0;
     uint32_t cu_count = 256;
+    uint32_t auto_streams = 1;
     char     kname[96] = {0};
     // timing
     std::vector<EventPair> ev_free, ev_pending;
@@ -153,18 +154,40 @@ int common_init(heat_cf_engine* e, const heat_cf_config* cfg, uint64_t data_rows
     const uint32_t coh = cfg->coherence == HEAT_CF_COHERENCE_DEFAULT ? HEAT_CF_COHERENCE_DEVICE : cfg->coherence;
     if (coh != HEAT_CF_COHERENCE_PLAIN && coh != HEAT_CF_COHERENCE_DEVICE) return fail(HEAT_CF_EINVAL, "bad coherence");
     e->aux = coh == HEAT_CF_COHERENCE_DEVICE ? 16 : 0;
+    // streams: enough sequential walkers to fill the chip, but never more asynchrony than was validated against the
+    // oracle at AmazonBooks shape (3072 streams over 91 599 items / 52 643 users)
+    {
+        const int lpr = e->lpr, ng = e->ng;
+        // measured register footprints: <=4 register groups fit 3 waves/SIMD, <=8 fit 2, the rest 1
+        const uint32_t waves_per_simd = ng <= 2 ? 4u : (ng <= 4 ? 3u : (ng <= 8 ? 2u : 1u));
+        (void)lpr;
+        uint64_t fill = (uint64_t)e->cu_count * 4ull * waves_per_simd;
+        const uint64_t cap_items = (uint64_t)(0.033 * (double)cfg->num_items);
+        const uint64_t cap_users = (uint64_t)(0.058 * (double)cfg->num_users);
+        uint64_t streams = std::min(fill, std::min(cap_items, cap_users));
+        if (streams < 1) streams = 1;
+        e->auto_streams = (uint32_t)streams;
+    }
     uint32_t um = cfg->update_mode;
-    if (um == HEAT_CF_UPDATE_DEFAULT) um = coh == HEAT_CF_COHERENCE_DEVICE ? HEAT_CF_UPDATE_ATOMIC_WG : HEAT_CF_UPDATE_OVERWRITE;
+    if (um == HEAT_CF_UPDATE_DEFAULT) um = HEAT_CF_UPDATE_AUTO;
+    if (coh != HEAT_CF_COHERENCE_DEVICE && um == HEAT_CF_UPDATE_AUTO) um = HEAT_CF_UPDATE_OVERWRITE;
+    if (um == HEAT_CF_UPDATE_AUTO)
+    {
+        const double streams = (double)(cfg->num_streams ? cfg->num_streams : e->auto_streams);
+        const double touches = streams * (double)cfg->num_negs / (double)cfg->num_items;
+        um = touches <= 0.55 ? HEAT_CF_UPDATE_ATOMIC_POS : HEAT_CF_UPDATE_ATOMIC_WG;
+    }
     uint32_t bits;
     if (um == HEAT_CF_UPDATE_OVERWRITE) bits = 0u;
     else if (um == HEAT_CF_UPDATE_ATOMIC_W) bits = 0x5u;
     else if (um == HEAT_CF_UPDATE_ATOMIC_WG) bits = 0xFu;
-    else if (um >= 16u && um < 32u) bits = um - 16u; // experimental: raw bit mask (bit0 neg W, bit1 neg G, bit2 pos W, bit3 pos G)
+    else if (um == HEAT_CF_UPDATE_ATOMIC_POS) bits = 0xCu;
+    else if (um >= 16u && um < 32u) bits = um - 16u;
     else return fail(HEAT_CF_EINVAL, "bad update_mode");
     if (bits != 0u && coh != HEAT_CF_COHERENCE_DEVICE)
         return fail(HEAT_CF_EINVAL, "atomic update modes need HEAT_CF_COHERENCE_DEVICE");
     e->upd = (int)bits;
-    std::snprintf(e->kname, sizeof(e->kname), "ccl_train_kernel<%d,%d,%d>", e->lpr, e->ng, e->aux);
+    std::snprintf(e->kname, sizeof(e->kname), "ccl_train_kernel<%d,%d,%d>/upd=0x%x", e->lpr, e->ng, e->aux, (unsigned)e->upd);
     HIP_TRY(hipMalloc(&e->d_sums, 2 * sizeof(double)));
     HIP_TRY(hipMemsetAsync(e->d_sums, 0, 2 * sizeof(double), e->stream));
     HIP_TRY(hipMalloc(&e->d_stats, 4 * sizeof(uint32_t)));
@@ -220,7 +243,7 @@ void geometry(const heat_cf_engine* e, uint64_t n, uint64_t* per_block, uint32_t
         *grid = 1;
         return;
     }
-    uint64_t streams = e->cfg.num_streams ? e->cfg.num_streams : (uint64_t)e->cu_count * 32ull;
+    uint64_t streams = e->cfg.num_streams ? e->cfg.num_streams : (uint64_t)e->auto_streams;
     uint64_t pb = (n + streams - 1) / streams;
     pb = ((pb + 63) / 64) * 64;
     if (pb == 0) pb = 64;

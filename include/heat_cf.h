@@ -50,12 +50,20 @@ extern "C" {
 #define HEAT_CF_COHERENCE_PLAIN   1 /* plain loads/stores: per-XCD L2 copies may diverge inside one launch      */
 #define HEAT_CF_COHERENCE_DEVICE  2 /* sc1 loads + sc1 write-through stores: coherent across the 8 XCDs         */
 
-/* how an item row's (W, G) update is written back (see DESIGN.md "Hogwild at GPU concurrency") */
-#define HEAT_CF_UPDATE_DEFAULT   0 /* engine picks (ATOMIC_WG when device-coherent)                                  */
-#define HEAT_CF_UPDATE_OVERWRITE 1 /* W <- W_read - lr*G, plain stores: the reference's literal memcpy write-back;
-                                      concurrent streams touching one row lose updates (last writer wins)          */
-#define HEAT_CF_UPDATE_ATOMIC_W  2 /* W += -lr*G by float atomic add (no update lost), G by plain store            */
-#define HEAT_CF_UPDATE_ATOMIC_WG 3 /* W as above, G += (G_new - G_read) by float atomic add                        */
+/* How an item row's (W, G) update is written back (DESIGN.md "Hogwild at GPU concurrency").  The reference writes
+ * rows back with memcpy (memory/array.hpp:52-55); with 8 CPU threads two workers almost never hold the same row, with
+ * thousands of concurrent GPU streams they constantly do, and a literal overwrite then drops most updates of popular
+ * rows.  Float atomic adds (W += -lr*G, G += G_new - G_read) lose nothing; they are bound by the memory-side atomic
+ * rate (~20 G 64-byte requests/s), so they are used where the measured conflict rate makes them necessary. */
+#define HEAT_CF_UPDATE_DEFAULT    0 /* = AUTO                                                                        */
+#define HEAT_CF_UPDATE_OVERWRITE  1 /* literal overwrite of W and G for every row (one stream per user run)          */
+#define HEAT_CF_UPDATE_ATOMIC_W   2 /* W by atomic add for every item row, G overwritten                             */
+#define HEAT_CF_UPDATE_ATOMIC_WG  3 /* W and G by atomic add for every item row: no update is ever lost              */
+#define HEAT_CF_UPDATE_ATOMIC_POS 4 /* positive item row: W and G by atomic add; negative rows: overwrite            */
+#define HEAT_CF_UPDATE_AUTO       5 /* ATOMIC_POS while the expected number of concurrent touches of a negative row,
+                                       streams * num_negs / num_items, is <= 0.55 (the regime validated against the
+                                       oracle), ATOMIC_WG otherwise                                                   */
+/* values 16..31: raw policy bits (16 + bit0 neg W atomic + bit1 neg G atomic + bit2 pos W atomic + bit3 pos G atomic) */
 
 /* Replaces cf::modules::CFConfig (modules/cf_config.hpp:12-35; bound at pybind/init_modules.cpp:13-33).
  * The first 13 fields are the reference's, in its constructor order.  The rest are extensions the
@@ -83,7 +91,9 @@ typedef struct heat_cf_config
     uint32_t flags;             /* HEAT_CF_FLAG_* */
     uint32_t coherence;         /* HEAT_CF_COHERENCE_* */
     int32_t  device;            /* HIP device ordinal; -1 = current device */
-    uint32_t num_streams;       /* concurrent sequential interaction streams (waves); 0 = auto */
+    uint32_t num_streams;       /* concurrent sequential interaction streams (waves); 0 = auto: what fills the GPU,
+                                   capped at 3.3 % of num_items / 5.8 % of num_users (the asynchrony validated at
+                                   AmazonBooks shape) */
     uint32_t update_mode;       /* HEAT_CF_UPDATE_* */
 } heat_cf_config;
 
