@@ -1,0 +1,117 @@
+"""The N>1 path on CPU: world_size-2 `gloo` runs of the item-table synchronisation (heat_amd/cf/distributed.py) with
+the oracle as the per-rank compute.  Checks user-range sharding (cf/main.py:51-57), that replicas agree after a sync,
+the `mean` rule (train/engine.cpp:366-375 intent) and the `sum` rule (every rank's delta applied)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from heat_amd.cf.distributed import shard_bounds, shard_clicks
+from oracle import cf_oracle as orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shard_bounds_partition_all_users():
+    for n, p in [(52643, 8), (10, 3), (7, 8), (100, 1), (29858, 4)]:
+        spans = [shard_bounds(n, p, r) for r in range(p)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(spans[i][1] == spans[i + 1][0] for i in range(p - 1))
+        sizes = [b - a for a, b in spans]
+        assert max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)   # main.py:51-57: first r ranks get +1
+
+
+def test_shard_clicks_rebases_users():
+    clicks = np.array([[0, 5], [0, 6], [1, 7], [3, 8], [4, 9], [4, 1]], dtype=np.uint64)
+    s0, lo0, hi0 = shard_clicks(clicks, 5, 2, 0)
+    s1, lo1, hi1 = shard_clicks(clicks, 5, 2, 1)
+    assert (lo0, hi0, lo1, hi1) == (0, 3, 3, 5)
+    assert s0.tolist() == [[0, 5], [0, 6], [1, 7]] and s1.tolist() == [[0, 8], [1, 9], [1, 1]]
+
+
+def make_problem(tmp_path, disjoint_items, epochs=2):
+    rng = np.random.default_rng(0)
+    U, I, d, N, T = 40, 200, 16, 4, 600
+    users = np.sort(rng.integers(0, U, T))
+    half = U // 2
+    if disjoint_items:
+        # users of rank 0 (ids < 20) only touch items < 100, rank 1 only items >= 100 -> the two replicas never
+        # write the same row and the `sum` rule must reproduce single-process training exactly
+        pos = np.where(users < half, rng.integers(0, I // 2, T), rng.integers(I // 2, I, T))
+        negs = np.where((users < half)[:, None], rng.integers(0, I // 2, (T, N)), rng.integers(I // 2, I, (T, N)))
+    else:
+        pos = rng.integers(0, I, T)
+        negs = rng.integers(0, I, (T, N))
+    clicks = np.stack([users, pos], axis=1).astype(np.uint64)
+    uw = (rng.standard_normal((U, d)) * 0.1).astype(np.float32)
+    iw = (rng.standard_normal((I, d)) * 0.1).astype(np.float32)
+    np.savez(tmp_path / "problem.npz", clicks=clicks, negs=negs.astype(np.uint64), uw=uw, iw=iw, num_users=U,
+             num_negs=N, lr=0.01, epochs=epochs)
+    return clicks, negs.astype(np.uint64), uw, iw, U, N
+
+
+def run_world(tmp_path, mode, window, world=2):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr",
+           "127.0.0.1", "--master-port", str(29500 + os.getpid() % 1000), os.path.join(ROOT, "tests", "_dist_worker.py"),
+           str(tmp_path), mode, str(window)]
+    res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout[-3000:]
+    return [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
+
+
+@pytest.mark.timeout(400)
+def test_sum_sync_equals_single_process_when_replicas_touch_disjoint_rows(tmp_path):
+    clicks, negs, uw, iw, U, N = make_problem(tmp_path, disjoint_items=True)
+    ranks = run_world(tmp_path, "sum", window=64)
+    assert np.array_equal(ranks[0]["iw"], ranks[1]["iw"])                 # replicas agree after the last sync
+    # single process, whole list, same negatives
+    u1, i1 = uw.copy(), iw.copy()
+    ref = orc.Engine(clicks, u1, i1, num_negs=N, l_r=0.01, clip_val=1.0)
+    for _ in range(2):
+        ref.lr_step()
+        ref.train_range(0, clicks.shape[0], negs)
+        ref.zero_grad()
+        ref.epoch = ref.epoch + 1
+    np.testing.assert_allclose(ranks[0]["iw"], i1, rtol=0, atol=1e-5)      # (W - ref) + ref costs 1 ulp per sync, carried through training
+    got_u = np.concatenate([ranks[0]["uw"], ranks[1]["uw"]])
+    np.testing.assert_allclose(got_u, u1, rtol=0, atol=1e-5)               # user rows are private (never communicated)
+
+
+@pytest.mark.timeout(400)
+def test_mean_sync_averages_replicas(tmp_path):
+    clicks, negs, uw, iw, U, N = make_problem(tmp_path, disjoint_items=False, epochs=1)
+    T = clicks.shape[0]
+    ranks = run_world(tmp_path, "mean", window=10 ** 9)                    # one sync, at the end of the epoch
+    assert np.array_equal(ranks[0]["iw"], ranks[1]["iw"])
+    # host-side restatement: train each shard alone on its own replica, then average (engine.cpp:366-375 intent)
+    reps = []
+    for r in range(2):
+        shard, lo, hi = shard_clicks(clicks, U, 2, r)
+        a = int(np.searchsorted(clicks[:, 0], lo))
+        u, i = uw[lo:hi].copy(), iw.copy()
+        e = orc.Engine(shard, u, i, num_negs=N, l_r=0.01, clip_val=1.0)
+        e.lr_step()
+        e.train_range(0, shard.shape[0], negs[a:a + shard.shape[0]])
+        reps.append(i)
+    np.testing.assert_allclose(ranks[0]["iw"], (reps[0] + reps[1]) / 2, rtol=0, atol=1e-7)
+
+
+@pytest.mark.timeout(400)
+def test_sum_sync_overlapping_rows_applies_both_deltas(tmp_path):
+    clicks, negs, uw, iw, U, N = make_problem(tmp_path, disjoint_items=False, epochs=1)
+    ranks = run_world(tmp_path, "sum", window=10 ** 9)
+    assert np.array_equal(ranks[0]["iw"], ranks[1]["iw"])
+    reps = []
+    for r in range(2):
+        shard, lo, hi = shard_clicks(clicks, U, 2, r)
+        a = int(np.searchsorted(clicks[:, 0], lo))
+        u, i = uw[lo:hi].copy(), iw.copy()
+        e = orc.Engine(shard, u, i, num_negs=N, l_r=0.01, clip_val=1.0)
+        e.lr_step()
+        e.train_range(0, shard.shape[0], negs[a:a + shard.shape[0]])
+        reps.append(i)
+    want = iw + (reps[0] - iw) + (reps[1] - iw)
+    np.testing.assert_allclose(ranks[0]["iw"], want, rtol=0, atol=3e-7)
