@@ -50,13 +50,14 @@ class ItemSync:
         if sync_interactions <= 0:
             streams = streams or getattr(engine, "num_streams", 0) or 3022
             sync_interactions = streams * refresh_interval
-        self.window = max(1, min(int(sync_interactions), n)) if n else 1
+        self.window = max(1, int(sync_interactions))   # clamped to the LARGEST shard inside train_one_epoch (same on every rank)
         self.ref = item_w.clone() if (mode == "sum" and world_size > 1) else None
         if mode not in ("sum", "mean"):
             raise ValueError("mode must be 'sum' or 'mean'")
 
     def describe(self):
-        return {"collective": "all_reduce(item table)", "mode": self.mode, "window_interactions_per_gpu": self.window}
+        return {"collective": "all_reduce(item table)", "mode": self.mode,
+                "window_interactions_per_gpu": min(self.window, self.engine.data_rows)}
 
     def sync(self):
         if self.world == 1:
@@ -82,11 +83,12 @@ class ItemSync:
             n_max = int(t.item())
         else:
             n_max = n
-        n_windows = max(1, -(-n_max // self.window))
+        window = min(self.window, max(1, n_max))
+        n_windows = max(1, -(-n_max // window))
         e.begin_epoch()
         for w in range(n_windows):
-            lo = min(n, w * self.window)
-            hi = min(n, (w + 1) * self.window)
+            lo = min(n, w * window)
+            hi = min(n, (w + 1) * window)
             if hi > lo:
                 e.train_range(lo, hi, want_loss=False)
             self.sync()

@@ -52,10 +52,17 @@ def make_problem(tmp_path, disjoint_items, epochs=2):
     return clicks, negs.astype(np.uint64), uw, iw, U, N
 
 
+def free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
 def run_world(tmp_path, mode, window, world=2):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr",
-           "127.0.0.1", "--master-port", str(29500 + os.getpid() % 1000), os.path.join(ROOT, "tests", "_dist_worker.py"),
+           "127.0.0.1", "--master-port", str(free_port()), os.path.join(ROOT, "tests", "_dist_worker.py"),
            str(tmp_path), mode, str(window)]
     res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
     assert res.returncode == 0, res.stdout[-3000:]
