@@ -119,6 +119,16 @@ def main():
         elapsed = float(t.item())
     kernel_ms, launches = eng.kernel_time()
 
+    traffic = None
+    pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if os.path.exists(pmc_path) and args.shape == "amazonbooks":
+        # HBM bytes per launch from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same command
+        # (tools/pmc_traffic.py; counters cannot be collected from inside the process being timed)
+        with open(pmc_path) as f:
+            pmc = json.load(f)
+        if pmc.get("kernel", "").split("/")[0] == eng.kernel_name.split("/")[0]:
+            traffic = pmc["traffic_bytes_per_launch"] / 1e9
+
     if rank == 0:
         total = world * T * args.steps
         B = 16 * d * (N + 2) + 16                 # algorithmic bytes per interaction
@@ -143,7 +153,8 @@ def main():
                        "kernel": eng.kernel_name,
                        "item_sync": None if trainer is None else trainer.describe()},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "GB per launch (PMC)",
+                         "algorithmic_gb_per_launch": B * inter_per_launch / 1e9,
                          "bytes_per_interaction": B, "kernel_ms_per_launch": per_launch_s * 1e3,
                          "launches": launches},
         }

@@ -1,0 +1,35 @@
+"""Turn the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs as MI355X_MICROARCH.md prescribes) into
+per-launch HBM traffic of the training kernel.  Corrections per that guide: both counters are in KiB; on gfx950
+FETCH_SIZE reports exactly half of the bytes of a wide (16 B/lane) coalesced read; WRITE_SIZE is exact for 16-B/lane
+stores and float atomics."""
+import csv
+import json
+import sys
+
+
+def mean_counter(path, counter, kernel_substr):
+    vals = []
+    with open(path) as f:
+        for row in csv.DictReader(f):
+            if row["Counter_Name"] == counter and kernel_substr in row["Kernel_Name"]:
+                vals.append(float(row["Counter_Value"]))
+    if not vals:
+        raise SystemExit(f"no {counter} rows for {kernel_substr} in {path}")
+    return sum(vals) / len(vals), len(vals)
+
+
+if __name__ == "__main__":
+    fetch_csv, write_csv, out = sys.argv[1], sys.argv[2], sys.argv[3]
+    fetch_kib, n1 = mean_counter(fetch_csv, "FETCH_SIZE", "ccl_train_kernel")
+    write_kib, n2 = mean_counter(write_csv, "WRITE_SIZE", "ccl_train_kernel")
+    res = {
+        "kernel": "ccl_train_kernel<16,4,16>", "workload": "bench.py default (AmazonBooks shape, 2380730 interactions per launch)",
+        "launches_averaged": [n1, n2],
+        "FETCH_SIZE_KiB_raw": fetch_kib, "WRITE_SIZE_KiB_raw": write_kib,
+        "fetch_bytes_per_launch": fetch_kib * 1024 * 2,     # gfx950: x2 for 16 B/lane reads
+        "write_bytes_per_launch": write_kib * 1024,
+    }
+    res["traffic_bytes_per_launch"] = res["fetch_bytes_per_launch"] + res["write_bytes_per_launch"]
+    res["algorithmic_bytes_per_launch"] = 18448 * 2380730
+    json.dump(res, open(out, "w"), indent=1)
+    print(json.dumps(res, indent=1))
