@@ -100,23 +100,31 @@ __device__ __forceinline__ void flush_user_row(const TrainArgs& a, uint32_t user
 // a.upd_bits selects, per kind of row, how the update is written back (wave-uniform branches):
 //   bit 0: negative W by atomic add   bit 1: negative G by atomic add
 //   bit 2: positive W by atomic add   bit 3: positive G by atomic add      (0 = the reference's literal overwrite)
-template <int LPR, int NG, int AUX>
-__global__ __launch_bounds__(64) void ccl_train_kernel(TrainArgs a)
+//
+// NW waves form one workgroup and share ONE interaction stream: wave w owns the negative slots
+// [w*NGW*R, (w+1)*NGW*R); user and positive rows are replicated in every wave's registers (every wave computes the
+// identical update of them, wave 0 writes them back).  Softmax statistics and the user-gradient partial sums cross
+// waves through LDS (2-3 workgroup barriers per interaction).  NW = 1 compiles all of that away.
+template <int LPR, int NGW, int AUX, int NW>
+__global__ __launch_bounds__(64 * NW) void ccl_train_kernel(TrainArgs a)
 {
     const bool neg_w_atomic = (a.upd_bits & 1u) != 0u, neg_g_atomic = (a.upd_bits & 2u) != 0u;
     const bool pos_w_atomic = (a.upd_bits & 4u) != 0u, pos_g_atomic = (a.upd_bits & 8u) != 0u;
     const bool any_atomic = a.upd_bits != 0u;
-    constexpr int R = 64 / LPR;          // rows fetched by one wave instruction
-    constexpr int NCAP = NG * R;         // negative slots held in registers
-    constexpr int NIDV = (NCAP + 63) / 64;
-    const int lane = (int)threadIdx.x;
-    const int sub = lane & (LPR - 1);    // 16-byte column of the row
-    const int rr = lane / LPR;           // which of the R rows of a group this lane serves
+    constexpr int R = 64 / LPR;            // rows fetched by one wave instruction
+    constexpr int WCAP = NGW * R;          // negative slots held by one wave
+    constexpr int NIDV = (WCAP + 63) / 64; // id registers per lane (lane k, register v: slot wave_base + v*64 + k)
+    constexpr int GPF = 4;                 // how many groups ahead the G rows may be fetched in the backward sweep
+    const int lane = (int)(threadIdx.x & 63u);
+    const int wave = NW == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t wave_base = (uint32_t)(wave * WCAP);
+    const int sub = lane & (LPR - 1);      // 16-byte column of the row
+    const int rr = lane / LPR;             // which of the R rows of a group this lane serves
     const uint32_t col_off = (uint32_t)sub * 16u;
     const bool col_ok = col_off < a.row_bytes;
     const uint32_t N = a.num_negs;
     const float lr = a.lr, clip = a.clip;
-    const float eps = 1e-8f;             // matrix_factorization.cpp:53
+    const float eps = 1e-8f;               // matrix_factorization.cpp:53
     const float score_mul = (float)(1.0 / 0.07); // :101-103 (double converted to the array's scalar type)
 
     const __amdgpu_buffer_rsrc_t item_w = make_rsrc(a.item_w, a.item_bytes);
@@ -130,7 +138,12 @@ __global__ __launch_bounds__(64) void ccl_train_kernel(TrainArgs a)
         first = align_to_user_run(a.clicks, first, a.begin, a.end, a.align_cap, lane);
         last = align_to_user_run(a.clicks, last, a.begin, a.end, a.align_cap, lane);
     }
-    __shared__ __attribute__((aligned(16))) float tile[256]; // one wave per workgroup: wave-private transpose tile
+    __shared__ __attribute__((aligned(16))) float tile_all[NW * 256]; // per-wave transpose tile for the atomics
+    __shared__ uint32_t sh_ids[NW > 1 ? NW * WCAP : 1];               // all negative ids of the interaction
+    __shared__ float sh_stat[NW > 1 ? NW * 2 : 1];                    // per-wave (max, sum of exp)
+    __shared__ __attribute__((aligned(16))) float sh_gu[NW > 1 ? NW * 64 * 4 : 4]; // per-wave user-gradient partials
+    __shared__ float sh_slg[NW > 1 ? NW : 1];
+    float* tile = tile_all + wave * 256;
     // A user run cut by a stream boundary is also being updated by the neighbouring stream: its row is then written
     // back as an atomic delta (nothing lost); a run owned entirely by this stream is written back with plain stores.
     uint32_t cut_head_user = 0xFFFFFFFFu, cut_tail_user = 0xFFFFFFFFu;
@@ -160,16 +173,25 @@ __global__ __launch_bounds__(64) void ccl_train_kernel(TrainArgs a)
             const uint32_t user = (uint32_t)__builtin_amdgcn_readlane((int)pair.x, j);
             const uint32_t pos = (uint32_t)__builtin_amdgcn_readlane((int)pair.y, j);
             const uint64_t idx = base + (uint64_t)j;
+            if (NW > 1)
+            {
+                // B0: the previous interaction's row writes of EVERY wave are performed before any wave gathers again
+                // (within one wave program order already guarantees this; across waves nothing does)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+            }
 
-            // ---- negatives: lane k (register v) owns slot v*64+k ---------------------------------------
+            // ---- negatives: lane k, register v owns slot wave_base + v*64 + k --------------------------------
 #pragma unroll
             for (int v = 0; v < NIDV; ++v)
             {
-                const uint32_t slot = (uint32_t)(v * 64 + lane);
+                const uint32_t wslot = (uint32_t)(v * 64 + lane);
+                const uint32_t slot = wave_base + wslot;
+                const bool mine = wslot < (uint32_t)WCAP && slot < N;
                 uint32_t id;
                 if (a.ext_negs != nullptr)
                 {
-                    id = slot < N ? a.ext_negs[(idx - a.ext_base) * N + slot] : 0u;
+                    id = mine ? a.ext_negs[(idx - a.ext_base) * N + slot] : 0u;
                 }
                 else
                 {
@@ -179,13 +201,14 @@ __global__ __launch_bounds__(64) void ccl_train_kernel(TrainArgs a)
                     if (!a.sampling_call && id == pos) id = nid[v];
                 }
                 nid[v] = id;
-                if (a.neg_out != nullptr && slot < N) a.neg_out[(idx - a.neg_out_base) * N + slot] = id;
+                if (a.neg_out != nullptr && mine) a.neg_out[(idx - a.neg_out_base) * N + slot] = id;
+                if (NW > 1 && mine) sh_ids[slot] = id;
             }
 
             // ---- user row: registers while the user does not change (write back on change) -----------------
             if (user != cur_user)
             {
-                if (cur_user != 0xFFFFFFFFu)
+                if (cur_user != 0xFFFFFFFFu && wave == 0)
                     flush_user_row<LPR, AUX>(a, cur_user, cur_user == cut_head_user || cur_user == cut_tail_user, u4, gu4,
                                              u4_in, gu4_in, tile, lane, rr, col_ok, col_off);
                 cur_user = user;
@@ -197,50 +220,55 @@ __global__ __launch_bounds__(64) void ccl_train_kernel(TrainArgs a)
                 gu4_in = gu4;
             }
 
-            // ---- gather: positive row (replicated in every row group) + N negative rows, W and G -----------
+            // ---- gather: positive row (replicated in every row group) + this wave's negative rows (W only; the
+            //      G rows are fetched a few groups ahead of their use in the backward sweep) ----------------------
             const uint32_t poff = col_ok ? pos * a.row_bytes + col_off : OOB_OFF;
             f32x4 p4 = buf_load<AUX>(item_w, poff);
             f32x4 gp4 = buf_load<AUX>(item_g, poff);
 
-            f32x4 n4[NG], gn4[NG];
-            uint32_t noff[NG];
-            bool valid[NG];
+            f32x4 n4[NGW];
+            uint32_t noff[NGW];
 #pragma unroll
-            for (int g = 0; g < NG; ++g)
+            for (int g = 0; g < NGW; ++g)
             {
-                const int k = g * R + rr;                    // slot of this lane's row in group g
-                const uint32_t id = lane_get(nid[(g * R) / 64], k & 63);
-                valid[g] = (uint32_t)k < N;
-                // a negative that equals the positive is not written: the positive's write-back comes last
-                // in the reference (matrix_factorization.cpp:171-174) and overwrites it
-                noff[g] = (valid[g] && col_ok) ? id * a.row_bytes + col_off : OOB_OFF;
+                const int wk = g * R + rr;                   // slot of this lane's row inside the wave
+                const uint32_t id = lane_get(nid[(g * R) / 64], wk & 63);
+                const bool valid = wave_base + (uint32_t)wk < N;
+                noff[g] = (valid && col_ok) ? id * a.row_bytes + col_off : OOB_OFF;
                 n4[g] = buf_load<AUX>(item_w, noff[g]);
-                gn4[g] = buf_load<AUX>(item_g, noff[g]);
-                if (id == pos) noff[g] = OOB_OFF;
             }
 
             // ---- duplicate negatives inside one interaction (rare): multiplicity per slot ------------------
             // Reference semantics (matrix_factorization.cpp:127-150): slot k re-reads G fresh, so c copies of one
             // row apply G <- clip(G + g) c times; every copy writes W_stale - lr*G, last writer wins.  All copies
             // compute the identical c-fold result here, so whichever store lands last is the reference's value.
-            uint32_t cmul[NG];
+            uint32_t eq[NIDV], earlier[NIDV];
             uint32_t cmax = 1u;
             {
-                uint32_t eq[NIDV], earlier[NIDV];
 #pragma unroll
                 for (int v = 0; v < NIDV; ++v) { eq[v] = 0u; earlier[v] = 0u; }
+                if (NW > 1) __syncthreads();                 // B1: every wave's ids are in sh_ids
                 for (uint32_t s = 0; s < N; ++s)
                 {
                     uint32_t sid = 0u;
+                    if (NW > 1)
+                    {
+                        sid = sh_ids[s];
+                    }
+                    else
+                    {
 #pragma unroll
-                    for (int v = 0; v < NIDV; ++v)
-                        if ((int)(s >> 6) == v) sid = (uint32_t)__builtin_amdgcn_readlane((int)nid[v], (int)(s & 63u));
+                        for (int v = 0; v < NIDV; ++v)
+                            if ((int)(s >> 6) == v) sid = (uint32_t)__builtin_amdgcn_readlane((int)nid[v], (int)(s & 63u));
+                    }
 #pragma unroll
                     for (int v = 0; v < NIDV; ++v)
                     {
-                        const bool same = nid[v] == sid && (uint32_t)(v * 64 + lane) < N;
+                        const uint32_t wslot = (uint32_t)(v * 64 + lane);
+                        const uint32_t slot = wave_base + wslot;
+                        const bool same = nid[v] == sid && wslot < (uint32_t)WCAP && slot < N;
                         eq[v] += same ? 1u : 0u;
-                        earlier[v] += (same && s < (uint32_t)(v * 64 + lane)) ? 1u : 0u;
+                        earlier[v] += (same && s < slot) ? 1u : 0u;
                     }
                 }
                 bool any_dup = false;
@@ -249,15 +277,7 @@ __global__ __launch_bounds__(64) void ccl_train_kernel(TrainArgs a)
                 if (__builtin_amdgcn_ballot_w64(any_dup) != 0ull)
                 {
 #pragma unroll
-                    for (int g = 0; g < NG; ++g)
-                    {
-                        cmul[g] = valid[g] ? lane_get(eq[(g * R) / 64], (g * R + rr) & 63) : 1u;
-                        cmax = cmul[g] > cmax ? cmul[g] : cmax;
-                        // with atomic W updates only the first copy of a duplicated row adds its (c-fold) delta: the
-                        // reference's copies all write the same W_stale - lr*G_c (last writer wins, one effective update)
-                        if (neg_w_atomic && lane_get(earlier[(g * R) / 64], (g * R + rr) & 63) != 0u) noff[g] = OOB_OFF;
-                    }
-                    // wave-uniform upper bound
+                    for (int v = 0; v < NIDV; ++v) cmax = eq[v] > cmax ? eq[v] : cmax;
 #pragma unroll
                     for (int m = 1; m < 64; m <<= 1)
                     {
@@ -265,11 +285,6 @@ __global__ __launch_bounds__(64) void ccl_train_kernel(TrainArgs a)
                         cmax = o > cmax ? o : cmax;
                     }
                     cmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)cmax); // provably uniform loop bound
-                }
-                else
-                {
-#pragma unroll
-                    for (int g = 0; g < NG; ++g) cmul[g] = 1u;
                 }
             }
 
@@ -285,28 +300,45 @@ __global__ __launch_bounds__(64) void ccl_train_kernel(TrainArgs a)
             const float r_u_p3 = 1.0f / (unorm * pnorm3);
             const float upcos = up / (unorm * pnorm);
 
-            float un[NG], nn[NG], nnorm[NG], score[NG];
+            float un[NGW], nn[NGW], es[NGW];
             float mx = -INFINITY;
 #pragma unroll
-            for (int g = 0; g < NG; ++g)
+            for (int g = 0; g < NGW; ++g)
             {
                 un[g] = row_sum<LPR>(dot4(u4, n4[g]));
                 nn[g] = row_sum<LPR>(dot4(n4[g], n4[g]));
-                nnorm[g] = sqrtf(nn[g] < eps ? eps : nn[g]);
-                const float c = un[g] / (unorm * nnorm[g]);
-                score[g] = valid[g] ? (c - upcos) * score_mul : -INFINITY;
-                mx = fmaxf(mx, score[g]);
+                const float nnorm = sqrtf(nn[g] < eps ? eps : nn[g]);
+                const float c = un[g] / (unorm * nnorm);
+                const bool valid = wave_base + (uint32_t)(g * R + rr) < N;
+                es[g] = valid ? (c - upcos) * score_mul : -INFINITY;    // the score; becomes exp(score - max) below
+                mx = fmaxf(mx, es[g]);
             }
             mx = cross_max<LPR>(mx);
-            float es[NG];
+            float wmx = mx;                                             // this wave's maximum
+            if (NW > 1)
+            {
+                if (lane == 0) sh_stat[wave * 2] = mx;
+                __syncthreads();                                        // B2a
+#pragma unroll
+                for (int w = 0; w < NW; ++w) mx = fmaxf(mx, sh_stat[w * 2]);
+            }
+            (void)wmx;
             float ssum = 0.0f;
 #pragma unroll
-            for (int g = 0; g < NG; ++g)
+            for (int g = 0; g < NGW; ++g)
             {
-                es[g] = valid[g] ? expf(score[g] - mx) : 0.0f;
+                es[g] = (es[g] == -INFINITY) ? 0.0f : expf(es[g] - mx);
                 ssum += es[g];
             }
             ssum = cross_sum<LPR>(ssum);
+            if (NW > 1)
+            {
+                if (lane == 0) sh_stat[wave * 2 + 1] = ssum;
+                __syncthreads();                                        // B2b
+                ssum = 0.0f;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) ssum += sh_stat[w * 2 + 1];
+            }
             // :106 adds exp(-max) computed in double; fp32 expf differs by <= 1 ulp of the sum
             const float Z = ssum + expf(-mx);
             const float loss = mx + logf(Z);
@@ -318,55 +350,89 @@ __global__ __launch_bounds__(64) void ccl_train_kernel(TrainArgs a)
             const f32x4 upp = -(pp * u4 - up * p4) * r_u_p3;
             f32x4 gu_acc = {0, 0, 0, 0};
             float slg = 0.0f;
+            f32x4 gpf[GPF];                                             // G rows in flight
 #pragma unroll
-            for (int g = 0; g < NG; ++g)
+            for (int g = 0; g < GPF && g < NGW; ++g) gpf[g] = buf_load<AUX>(item_g, noff[g]);
+#pragma unroll
+            for (int g = 0; g < NGW; ++g)
             {
+                const f32x4 g_read = gpf[g % GPF];
+                if (g + GPF < NGW) gpf[g % GPF] = buf_load<AUX>(item_g, noff[g + GPF]);
                 const float lg = (es[g] / Z) * score_mul;                       // :109
-                const float nnorm3 = nnorm[g] * nnorm[g] * nnorm[g];
-                const float r_u3_n = 1.0f / (unorm3 * nnorm[g]);                // :136
+                const float nnorm = sqrtf(nn[g] < eps ? eps : nn[g]);
+                const float nnorm3 = nnorm * nnorm * nnorm;
+                const float r_u3_n = 1.0f / (unorm3 * nnorm);                   // :136
                 const float r_u_n3 = 1.0f / (unorm * nnorm3);                   // :137
                 const f32x4 unu = (uu * n4[g] - un[g] * u4) * r_u3_n;           // :138
                 const f32x4 unn = (nn[g] * u4 - un[g] * n4[g]) * r_u_n3;        // :139 (raw nn, not eps-clamped)
                 gu_acc += lg * (unu - upu);                                     // :141
                 slg += lg;                                                      // :142 (pos grad += lg * upp)
                 const f32x4 t = lg * unn;
-                f32x4 gn = clip4(gn4[g] + t, clip);                             // :143,147 + sgd.cpp:22
-                for (uint32_t c = 1; c < cmax; ++c)
+                f32x4 gn = clip4(g_read + t, clip);                             // :143,147 + sgd.cpp:22
+                uint32_t woff = noff[g];
+                if (cmax > 1u)                                                  // duplicates present (wave-uniform)
                 {
-                    const f32x4 g2 = clip4(gn + t, clip);
-                    if (c < cmul[g]) gn = g2;
+                    const int src = (g * R + rr) & 63;
+                    const uint32_t cm = lane_get(eq[(g * R) / 64], src);
+                    for (uint32_t c = 1; c < cmax; ++c)
+                    {
+                        const f32x4 g2 = clip4(gn + t, clip);
+                        if (c < cm) gn = g2;
+                    }
+                    // only the first copy of a duplicated row writes its (c-fold) result: the reference's copies all
+                    // write the same W_stale - lr*G_c / G_c (last writer wins = one effective update), and a later
+                    // copy's streamed G fetch may already see the first copy's write
+                    if (lane_get(earlier[(g * R) / 64], src) != 0u) woff = OOB_OFF;
                 }
+                // a negative that equals the positive is not written: the positive's write-back comes last in the
+                // reference (matrix_factorization.cpp:171-174) and overwrites it
+                if (woff != OOB_OFF && woff - col_off == pos * a.row_bytes) woff = OOB_OFF;
                 if (!neg_w_atomic && !neg_g_atomic)
                 {
-                    buf_store<AUX>(item_w, noff[g], n4[g] - lr * gn);           // sgd.cpp:23, :148
-                    buf_store<AUX>(item_g, noff[g], gn);                        // :149
+                    buf_store<AUX>(item_w, woff, n4[g] - lr * gn);              // sgd.cpp:23, :148
+                    buf_store<AUX>(item_g, woff, gn);                           // :149
                 }
                 else
                 {
-                    const AtomicOffsets ao = atomic_offsets(noff[g], lane);
+                    const AtomicOffsets ao = atomic_offsets(woff, lane);
                     if (neg_w_atomic) atomic_add_tile<4>(item_w, ao, -(lr * gn), tile, lane); // W += -(lr*G)
-                    else buf_store<AUX>(item_w, noff[g], n4[g] - lr * gn);
-                    if (neg_g_atomic) atomic_add_tile<4>(item_g, ao, gn - gn4[g], tile, lane);
-                    else buf_store<AUX>(item_g, noff[g], gn);
+                    else buf_store<AUX>(item_w, woff, n4[g] - lr * gn);
+                    if (neg_g_atomic) atomic_add_tile<4>(item_g, ao, gn - g_read, tile, lane);
+                    else buf_store<AUX>(item_g, woff, gn);
                 }
+                if ((g % GPF) == GPF - 1) __builtin_amdgcn_sched_barrier(0);    // bound how far G fetches are hoisted
             }
             gu_acc.x = cross_sum<LPR>(gu_acc.x);
             gu_acc.y = cross_sum<LPR>(gu_acc.y);
             gu_acc.z = cross_sum<LPR>(gu_acc.z);
             gu_acc.w = cross_sum<LPR>(gu_acc.w);
             slg = cross_sum<LPR>(slg);
+            if (NW > 1)
+            {
+                *reinterpret_cast<f32x4*>(sh_gu + (wave * 64 + lane) * 4) = gu_acc;
+                if (lane == 0) sh_slg[wave] = slg;
+                __syncthreads();                                                // B3
+                gu_acc = f32x4{0, 0, 0, 0};
+                slg = 0.0f;
+#pragma unroll
+                for (int w = 0; w < NW; ++w)
+                {
+                    gu_acc += *reinterpret_cast<const f32x4*>(sh_gu + (w * 64 + lane) * 4);
+                    slg += sh_slg[w];
+                }
+            }
 
             gu4 = clip4(gu4 + gu_acc, clip);                                    // :166
             u4 = u4 - lr * gu4;
             const f32x4 gp_old = gp4;
             gp4 = clip4(gp4 + slg * upp, clip);                                 // :169
-            const uint32_t pst = (rr == 0 && col_ok) ? pos * a.row_bytes + col_off : OOB_OFF;
+            const uint32_t pst = (wave == 0 && rr == 0 && col_ok) ? pos * a.row_bytes + col_off : OOB_OFF;
             if (!pos_w_atomic && !pos_g_atomic)
             {
                 buf_store<AUX>(item_w, pst, p4 - lr * gp4);                     // :173
                 buf_store<AUX>(item_g, pst, gp4);                               // :174
             }
-            else
+            else if (wave == 0)
             {
                 constexpr int NCH = LPR >= 16 ? LPR / 16 : 1;                   // row 0 of the tile only
                 const AtomicOffsets ao = atomic_offsets(pst, lane);
@@ -378,10 +444,10 @@ __global__ __launch_bounds__(64) void ccl_train_kernel(TrainArgs a)
         }
     }
 
-    if (cur_user != 0xFFFFFFFFu)                                                           // :171-172
+    if (cur_user != 0xFFFFFFFFu && wave == 0)                                              // :171-172
         flush_user_row<LPR, AUX>(a, cur_user, cur_user == cut_head_user || cur_user == cut_tail_user, u4, gu4, u4_in,
                                  gu4_in, tile, lane, rr, col_ok, col_off);
-    if (lane == 0) a.loss_part[blockIdx.x] = loss_acc;
+    if (wave == 0 && lane == 0) a.loss_part[blockIdx.x] = loss_acc;
 }
 
 // Deterministic fixed-order reduction of the per-stream loss partials (fp64), accumulated into *out.
@@ -442,43 +508,52 @@ __global__ __launch_bounds__(64) void sample_negs_kernel(TrainArgs a, uint64_t o
 }
 
 // ---- dispatch -------------------------------------------------------------------------------------------------
-template <int LPR, int NG>
+template <int LPR, int NGW, int NW>
 static hipError_t launch_variant(const TrainArgs& a, uint32_t grid, int aux, hipStream_t s)
 {
     if (aux == AUX_PLAIN)
-        hipLaunchKernelGGL((ccl_train_kernel<LPR, NG, AUX_PLAIN>), dim3(grid), dim3(64), 0, s, a);
+        hipLaunchKernelGGL((ccl_train_kernel<LPR, NGW, AUX_PLAIN, NW>), dim3(grid), dim3(64 * NW), 0, s, a);
     else
-        hipLaunchKernelGGL((ccl_train_kernel<LPR, NG, AUX_SC1>), dim3(grid), dim3(64), 0, s, a);
+        hipLaunchKernelGGL((ccl_train_kernel<LPR, NGW, AUX_SC1, NW>), dim3(grid), dim3(64 * NW), 0, s, a);
     return hipGetLastError();
 }
 
+// (lanes per row, register groups per wave, waves per workgroup): capacity = NGW * (64/LPR) * NW negatives.
+// Per-wave register budget ~ 8 VGPRs per group + ~60; more waves per workgroup instead of more groups per wave once a
+// wave would need > ~20 groups.
 #define HEATCF_VARIANTS(X) \
-    X(8, 1) X(8, 2) X(8, 4) \
-    X(16, 2) X(16, 4) X(16, 8) X(16, 16) X(16, 25) \
-    X(32, 4) X(32, 8) X(32, 16) X(32, 32) \
-    X(64, 8) X(64, 16) X(64, 32)
+    X(8, 1, 1) X(8, 2, 1) X(8, 4, 1) X(8, 8, 1) X(8, 16, 1) \
+    X(16, 2, 1) X(16, 4, 1) X(16, 8, 1) X(16, 16, 1) X(16, 16, 2) \
+    X(32, 4, 1) X(32, 8, 1) X(32, 16, 1) X(32, 16, 2) X(32, 16, 4) \
+    X(64, 8, 1) X(64, 16, 1) X(64, 16, 2) X(64, 16, 4) X(64, 16, 8)
 
-bool pick_variant(uint32_t emb_dim, uint32_t num_negs, int* lpr_out, int* ng_out)
+bool pick_variant(uint32_t emb_dim, uint32_t num_negs, int* lpr_out, int* ng_out, int* nw_out)
 {
     if (emb_dim == 0 || emb_dim % 4 != 0 || emb_dim > 256 || num_negs == 0) return false;
     const uint32_t need = emb_dim / 4;
     int lpr = 8;
     while ((uint32_t)lpr < need) lpr <<= 1;
     const int R = 64 / lpr;
-    const int need_ng = (int)((num_negs + R - 1) / R);
-    int best = 0;
-#define X(L, G) if (L == lpr && G >= need_ng && (best == 0 || G < best)) best = G;
+    int best_cap = 0, best_g = 0, best_w = 0;
+#define X(L, G, W)                                                                                   \
+    if (L == lpr && (uint32_t)(G * R * W) >= num_negs && (best_cap == 0 || G * R * W < best_cap))      \
+    {                                                                                                  \
+        best_cap = G * R * W;                                                                          \
+        best_g = G;                                                                                    \
+        best_w = W;                                                                                    \
+    }
     HEATCF_VARIANTS(X)
 #undef X
-    if (best == 0) return false;
+    if (best_cap == 0) return false;
     *lpr_out = lpr;
-    *ng_out = best;
+    *ng_out = best_g;
+    *nw_out = best_w;
     return true;
 }
 
-hipError_t launch_train(const TrainArgs& a, int lpr, int ng, uint32_t grid, int aux, hipStream_t s)
+hipError_t launch_train(const TrainArgs& a, int lpr, int ng, int nw, uint32_t grid, int aux, hipStream_t s)
 {
-#define X(L, G) if (lpr == L && ng == G) return launch_variant<L, G>(a, grid, aux, s);
+#define X(L, G, W) if (lpr == L && ng == G && nw == W) return launch_variant<L, G, W>(a, grid, aux, s);
     HEATCF_VARIANTS(X)
 #undef X
     return hipErrorInvalidValue;

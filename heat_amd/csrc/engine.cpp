@@ -76,7 +76,7 @@ struct heat_cf_engine
     float    lr = 0.f;
     uint64_t epoch = 0;
     // kernel choice
-    int      lpr = 0, ng = 0, aux = 0, upd = 0;
+    int      lpr = 0, ng = 0, nw = 1, aux = 0, upd = 0;
     uint32_t cu_count = 256;
     uint32_t auto_streams = 1;
     char     kname[96] = {0};
@@ -91,7 +91,7 @@ namespace
 size_t user_bytes(const heat_cf_engine* e) { return (size_t)e->cfg.num_users * e->cfg.emb_dim * sizeof(float); }
 size_t item_bytes(const heat_cf_engine* e) { return (size_t)e->cfg.num_items * e->cfg.emb_dim * sizeof(float); }
 
-int validate_cfg(const heat_cf_config* cfg, uint64_t data_rows, int* lpr, int* ng)
+int validate_cfg(const heat_cf_config* cfg, uint64_t data_rows, int* lpr, int* ng, int* nw)
 {
     if (!cfg) return fail(HEAT_CF_EINVAL, "cfg is NULL");
     if (cfg->num_users == 0 || cfg->num_items == 0) return fail(HEAT_CF_EINVAL, "num_users and num_items must be > 0");
@@ -108,7 +108,7 @@ int validate_cfg(const heat_cf_config* cfg, uint64_t data_rows, int* lpr, int* n
         return fail(HEAT_CF_EINVAL, "milestones[0] must be > 0 (optimizer.cpp:26 computes epoch % step_size)");
     if (cfg->use_aggregator) return fail(HEAT_CF_EUNSUP, "behaviour aggregation (ACCL) is not built yet");
     if (cfg->neg_sampler != 0 && cfg->neg_sampler != 1) return fail(HEAT_CF_EINVAL, "neg_sampler must be 0 or 1");
-    if (!pick_variant((uint32_t)cfg->emb_dim, (uint32_t)cfg->num_negs, lpr, ng))
+    if (!pick_variant((uint32_t)cfg->emb_dim, (uint32_t)cfg->num_negs, lpr, ng, nw))
         return fail(HEAT_CF_EUNSUP, "no compiled kernel variant for this (emb_dim, num_negs)");
     if (data_rows >= (1ull << 40)) return fail(HEAT_CF_EINVAL, "data_rows too large");
     return HEAT_CF_OK;
@@ -159,9 +159,12 @@ int common_init(heat_cf_engine* e, const heat_cf_config* cfg, uint64_t data_rows
     {
         const int lpr = e->lpr, ng = e->ng;
         // measured register footprints: <=4 register groups fit 3 waves/SIMD, <=8 fit 2, the rest 1
-        const uint32_t waves_per_simd = ng <= 2 ? 4u : (ng <= 4 ? 3u : (ng <= 8 ? 2u : 1u));
+        // register footprint ~ 8 VGPRs per group + ~60: waves per SIMD the kernel can hold
+        const uint32_t vg = 60u + 8u * (uint32_t)ng;
+        const uint32_t waves_per_simd = vg <= 64 ? 8u : (vg <= 96 ? 5u : (vg <= 128 ? 4u : (vg <= 168 ? 3u : (vg <= 256 ? 2u : 1u))));
         (void)lpr;
-        uint64_t fill = (uint64_t)e->cu_count * 4ull * waves_per_simd;
+        uint64_t fill = (uint64_t)e->cu_count * 4ull * waves_per_simd / (uint64_t)e->nw;   // workgroups (= streams)
+        if (fill < e->cu_count) fill = e->cu_count;
         const uint64_t cap_items = (uint64_t)(0.033 * (double)cfg->num_items);
         const uint64_t cap_users = (uint64_t)(0.058 * (double)cfg->num_users);
         uint64_t streams = std::min(fill, std::min(cap_items, cap_users));
@@ -187,7 +190,7 @@ int common_init(heat_cf_engine* e, const heat_cf_config* cfg, uint64_t data_rows
     if (bits != 0u && coh != HEAT_CF_COHERENCE_DEVICE)
         return fail(HEAT_CF_EINVAL, "atomic update modes need HEAT_CF_COHERENCE_DEVICE");
     e->upd = (int)bits;
-    std::snprintf(e->kname, sizeof(e->kname), "ccl_train_kernel<%d,%d,%d>/upd=0x%x", e->lpr, e->ng, e->aux, (unsigned)e->upd);
+    std::snprintf(e->kname, sizeof(e->kname), "ccl_train_kernel<%d,%d,%d,%d>/upd=0x%x", e->lpr, e->ng, e->aux, e->nw, (unsigned)e->upd);
     HIP_TRY(hipMalloc(&e->d_sums, 2 * sizeof(double)));
     HIP_TRY(hipMemsetAsync(e->d_sums, 0, 2 * sizeof(double), e->stream));
     HIP_TRY(hipMalloc(&e->d_stats, 4 * sizeof(uint32_t)));
@@ -324,8 +327,8 @@ int heat_cf_engine_create(const heat_cf_config* cfg, const uint64_t* clicks, uin
     (void)his; (void)max_his; (void)masks;
     if (!out) return fail(HEAT_CF_EINVAL, "out is NULL");
     *out = nullptr;
-    int lpr = 0, ng = 0;
-    int rc = validate_cfg(cfg, data_rows, &lpr, &ng);
+    int lpr = 0, ng = 0, nw = 1;
+    int rc = validate_cfg(cfg, data_rows, &lpr, &ng, &nw);
     if (rc) return rc;
     if (!clicks && data_rows) return fail(HEAT_CF_EINVAL, "clicks is NULL");
     if (!user_w || !item_w) return fail(HEAT_CF_EINVAL, "user_w / item_w is NULL");
@@ -345,6 +348,7 @@ int heat_cf_engine_create(const heat_cf_config* cfg, const uint64_t* clicks, uin
     if (!e) return fail(HEAT_CF_ENOMEM, "host allocation failed");
     e->lpr = lpr;
     e->ng = ng;
+    e->nw = nw;
     e->host_mode = true;
     e->h_user_w = user_w;
     e->h_item_w = item_w;
@@ -388,8 +392,8 @@ int heat_cf_engine_create_device(const heat_cf_config* cfg, const void* d_clicks
     (void)d_his; (void)max_his; (void)d_masks;
     if (!out) return fail(HEAT_CF_EINVAL, "out is NULL");
     *out = nullptr;
-    int lpr = 0, ng = 0;
-    int rc = validate_cfg(cfg, data_rows, &lpr, &ng);
+    int lpr = 0, ng = 0, nw = 1;
+    int rc = validate_cfg(cfg, data_rows, &lpr, &ng, &nw);
     if (rc) return rc;
     if (!d_clicks && data_rows) return fail(HEAT_CF_EINVAL, "d_clicks is NULL");
     if (!d_user_w || !d_item_w) return fail(HEAT_CF_EINVAL, "d_user_w / d_item_w is NULL");
@@ -398,6 +402,7 @@ int heat_cf_engine_create_device(const heat_cf_config* cfg, const void* d_clicks
     if (!e) return fail(HEAT_CF_ENOMEM, "host allocation failed");
     e->lpr = lpr;
     e->ng = ng;
+    e->nw = nw;
     e->host_mode = false;
     CREATE_TRY(common_init(e, cfg, data_rows, stream));
     auto body = [&]() -> int {
@@ -488,7 +493,7 @@ int heat_cf_train_range(heat_cf_engine* e, uint64_t begin, uint64_t end, const u
     rc = get_events(e, &ev);
     if (rc) return rc;
     HIP_TRY(hipEventRecord(ev.a, e->stream));
-    HIP_TRY(launch_train(a, e->lpr, e->ng, grid, e->aux, e->stream));
+    HIP_TRY(launch_train(a, e->lpr, e->ng, e->nw, grid, e->aux, e->stream));
     HIP_TRY(hipEventRecord(ev.b, e->stream));
     e->ev_pending.push_back(ev);
     e->launches += 1;

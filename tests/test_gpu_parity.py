@@ -55,7 +55,9 @@ def assert_tables_close(a, b, scale, rtol=2e-4):
     (256, 16, 20, 300, 600),     # <64,16>
     (64, 5, 30, 200, 1000),      # masked negative slots (N not a multiple of rows-per-instruction)
     (20, 3, 25, 300, 800),       # masked columns (emb_dim/4 = 5 of 8 lanes)
-    (64, 100, 20, 2000, 300),    # <16,25>, two id registers per lane
+    (64, 100, 20, 2000, 300),    # <16,16> x 2 waves per workgroup
+    (256, 100, 12, 3000, 150),   # synthetic-HBM config: <64,16> x 8 waves per workgroup
+    (128, 100, 12, 3000, 150),   # <32,16> x 4 waves
 ])
 def test_serial_walk_matches_oracle(d, N, U, I, T):
     clicks, uw, iw = small_problem(U, I, T, d, seed=d * 7 + N)
@@ -160,34 +162,44 @@ def test_epoch_protocol_lr_schedule_zero_grad_and_inplace_weights():
 def test_recall_ndcg_parity_amazonbooks_shape():
     """The north-star parity criterion: Recall@20 / NDCG@20 of the Hogwild GPU engine (thousands of concurrent
     streams, on-GPU Philox negatives) vs the CPU oracle (8 OpenMP threads, mt19937_64 negatives) within +-1e-3 after the
-    yaml's 5 epochs, same synthetic AmazonBooks-shaped graph, same N(0,0.01^2) tables, seed 2022.  The two runs draw
-    different negatives and interleave differently, so this is a statistical comparison; epoch losses within 4 %."""
+    yaml's 5 epochs, same synthetic AmazonBooks-shaped graph, same N(0,0.01^2) tables, seed 2022.  The runs draw different
+    negatives and interleave differently, and the 8-thread oracle itself is not reproducible (dynamic scheduling moves its
+    NDCG@20 by ~1e-3 between runs), so the GPU is compared with the MEAN of three oracle runs; epoch losses within 4 %."""
     import types
     from heat_amd.cf import metrics
     g, d, N = synthetic.make_named("amazonbooks")
-    uw, iw = synthetic.init_embeddings(g.num_users, g.num_items, d, seed=2022)
-    uo, io = uw.copy(), iw.copy()
-    eng = abi.Engine(g.clicks, uw, iw, num_negs=N, seed=2022, flags=abi.FLAG_LAZY_SYNC)
-    ora = orc.Engine(g.clicks, uo, io, num_negs=N)
-    lg = [eng.train_one_epoch() for _ in range(5)]
-    lo = [ora.train_one_epoch(num_threads=8) for _ in range(5)]
-    eng.sync_to_host()
-    for a, b in zip(lg, lo):
-        assert abs(a - b) <= 0.04 * b, (lg, lo)
+    uw0, iw0 = synthetic.init_embeddings(g.num_users, g.num_items, d, seed=2022)
     ep = g.test_indptr.astype(np.int64)
     test = types.SimpleNamespace(user_items_dic={u: g.test_items[ep[u]:ep[u + 1]].tolist()
                                                  for u in range(g.num_users) if ep[u + 1] > ep[u]})
     ms = ["Recall(k=20)", "NDCG(k=20)"]
-    top_g = eng.topk(20, mask_indptr=g.train_indptr, mask_items=g.train_items)
-    ev = abi.Engine(g.clicks[:1].copy(), uo, io, num_negs=N)     # the oracle's tables, ranked by the same top-k kernel
-    top_o = ev.topk(20, mask_indptr=g.train_indptr, mask_items=g.train_items)
-    rg = metrics.evaluate_topk(test, top_g, ms, quiet=True, by_user_id=True)
-    ro = metrics.evaluate_topk(test, top_o, ms, quiet=True, by_user_id=True)
-    print("gpu", lg, rg, "oracle", lo, ro)
+
+    def rank_and_score(uw, iw):
+        ev = abi.Engine(g.clicks[:1].copy(), uw, iw, num_negs=N)   # both sides are ranked by the same top-k kernel
+        top = ev.topk(20, mask_indptr=g.train_indptr, mask_items=g.train_items)
+        ev.close()
+        return metrics.evaluate_topk(test, top, ms, quiet=True, by_user_id=True)
+
+    uw, iw = uw0.copy(), iw0.copy()
+    eng = abi.Engine(g.clicks, uw, iw, num_negs=N, seed=2022, flags=abi.FLAG_LAZY_SYNC)
+    lg = [eng.train_one_epoch() for _ in range(5)]
+    eng.sync_to_host()
+    eng.close()
+    rg = rank_and_score(uw, iw)
+    ro_runs, lo_runs = [], []
+    for _ in range(3):
+        uo, io = uw0.copy(), iw0.copy()
+        ora = orc.Engine(g.clicks, uo, io, num_negs=N)
+        lo_runs.append([ora.train_one_epoch(num_threads=8) for _ in range(5)])
+        ro_runs.append(rank_and_score(uo, io))
+    lo = np.mean(lo_runs, axis=0)
+    ro = {m: float(np.mean([r[m] for r in ro_runs])) for m in ms}
+    print("gpu", lg, rg, "oracle runs", lo_runs, ro_runs)
+    for a, b in zip(lg, lo):
+        assert abs(a - b) <= 0.04 * b, (lg, lo)
     assert ro[ms[0]] > 0.05                                       # the model learned something
-    assert abs(rg[ms[0]] - ro[ms[0]]) <= 1e-3, (rg, ro)
-    assert abs(rg[ms[1]] - ro[ms[1]]) <= 1e-3, (rg, ro)
-    eng.close(); ev.close()
+    assert abs(rg[ms[0]] - ro[ms[0]]) <= 1e-3, (rg, ro_runs)
+    assert abs(rg[ms[1]] - ro[ms[1]]) <= 1e-3, (rg, ro_runs)
 
 
 def test_overwrite_mode_loses_updates_at_gpu_concurrency():
