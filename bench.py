@@ -54,6 +54,8 @@ def main():
     ap.add_argument("--sync-interactions", type=int, default=0,
                     help="interactions per GPU between item-table all-reduces (0 = streams x refresh_interval, see DESIGN.md)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--interactions", type=int, default=0,
+                    help="interactions per step for --shape synthetic_hbm (0 = 20 000 000: a sample of the 200 M list)")
     args = ap.parse_args()
 
     import torch
@@ -76,12 +78,24 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     U, I, T, d, N = synthetic.SHAPES[args.shape]
-    # every rank generates its own shard (different seed = different users), same item id space
-    graph = synthetic.make_graph(U, I, T, seed=2022 + rank, with_test=False)
-    uw_h, iw_h = synthetic.init_embeddings(U, I, d, seed=2022)
-    clicks = torch.from_numpy(graph.clicks.view(np.int64)).to(dev)
-    user_w = torch.from_numpy(uw_h).to(dev)
-    item_w = torch.from_numpy(iw_h).to(dev)       # identical on every rank (replicated table)
+    graph = None
+    if args.shape == "synthetic_hbm":
+        # BASELINE.json configs[4]: 10 M users x 1 M items, d=256, negs=100 (tables 22.5 GB: the true HBM-resident run).
+        # A step walks a 20 M-interaction sample of the 200 M list (a full pass is 83.6 TB of algorithmic traffic).
+        T = args.interactions or 20_000_000
+        clicks = synthetic.make_clicks_torch(U, I, T, dev, seed=2022 + rank)
+        g = torch.Generator(device=dev)
+        g.manual_seed(2022)
+        user_w = torch.empty((U, d), device=dev, dtype=torch.float32).normal_(0.0, 0.01, generator=g)
+        item_w = torch.empty((I, d), device=dev, dtype=torch.float32).normal_(0.0, 0.01, generator=g)
+        args.no_cpu_baseline = True
+    else:
+        # every rank generates its own shard (different seed = different users), same item id space
+        graph = synthetic.make_graph(U, I, T, seed=2022 + rank, with_test=False)
+        uw_h, iw_h = synthetic.init_embeddings(U, I, d, seed=2022)
+        clicks = torch.from_numpy(graph.clicks.view(np.int64)).to(dev)
+        user_w = torch.from_numpy(uw_h).to(dev)
+        item_w = torch.from_numpy(iw_h).to(dev)       # identical on every rank (replicated table)
     stream = torch.cuda.current_stream().cuda_stream
     eng = abi.Engine.from_device(clicks.data_ptr(), T, user_w.data_ptr(), item_w.data_ptr(), num_users=U, num_items=I,
                                  emb_dim=d, num_negs=N, stream=stream, keep=(clicks, user_w, item_w), seed=2022,
@@ -126,7 +140,7 @@ def main():
         # (tools/pmc_traffic.py; counters cannot be collected from inside the process being timed)
         with open(pmc_path) as f:
             pmc = json.load(f)
-        if pmc.get("kernel", "").split("/")[0] == eng.kernel_name.split("/")[0]:
+        if eng.kernel_name.startswith(pmc.get("kernel", "?").rstrip(">")):
             traffic = pmc["traffic_bytes_per_launch"] / 1e9
 
     if rank == 0:
@@ -136,7 +150,8 @@ def main():
         inter_per_launch = T * args.steps / max(launches, 1)
         achieved = B * inter_per_launch / per_launch_s / 1e9
         out = {
-            "metric": "positive-samples/sec/node (AmazonBooks d=64, negs=16)",
+            "metric": "positive-samples/sec/node (AmazonBooks d=64, negs=16)" if args.shape == "amazonbooks"
+            else f"positive-samples/sec/node ({args.shape} d={d}, negs={N})",
             "value": total / elapsed,
             "unit": "samples/s",
             "n_gpus": world,

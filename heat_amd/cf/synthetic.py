@@ -167,3 +167,23 @@ def init_embeddings(num_users, num_items, emb_dim, seed=2022, std=1e-2):
     uw = (rng.standard_normal((num_users, emb_dim), dtype=np.float32) * np.float32(std))
     iw = (rng.standard_normal((num_items, emb_dim), dtype=np.float32) * np.float32(std))
     return np.ascontiguousarray(uw), np.ascontiguousarray(iw)
+
+
+def make_clicks_torch(num_users, num_items, n, device, seed=2022, zipf_s=1.0):
+    """Interaction list for shapes too large for the numpy generator (synthetic-HBM config: 10 M users x 1 M items):
+    built on the GPU with torch, returned as an int64 [n,2] tensor (same bit pattern as the u64 pairs of the C ABI),
+    grouped by user, item popularity Zipf(s) over a random permutation.  (user,item) pairs may repeat; there is no
+    test split — this generator feeds bandwidth measurements, not Recall."""
+    import torch
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed)
+    users = torch.randint(0, num_users, (n,), device=device, generator=gen, dtype=torch.int64)
+    users, _ = torch.sort(users)
+    ranks = torch.arange(1, num_items + 1, device=device, dtype=torch.float64)
+    cdf = torch.cumsum(ranks.pow(-zipf_s), 0)
+    cdf /= cdf[-1].clone()
+    perm = torch.randperm(num_items, device=device, generator=gen)
+    r = torch.rand((n,), device=device, generator=gen, dtype=torch.float64)
+    items = perm[torch.searchsorted(cdf, r).clamp_(0, num_items - 1)]
+    del r, cdf, ranks
+    return torch.stack([users, items], dim=1).contiguous()

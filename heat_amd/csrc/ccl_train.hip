@@ -525,7 +525,7 @@ static hipError_t launch_variant(const TrainArgs& a, uint32_t grid, int aux, hip
     X(8, 1, 1) X(8, 2, 1) X(8, 4, 1) X(8, 8, 1) X(8, 16, 1) \
     X(16, 2, 1) X(16, 4, 1) X(16, 8, 1) X(16, 16, 1) X(16, 16, 2) \
     X(32, 4, 1) X(32, 8, 1) X(32, 16, 1) X(32, 16, 2) X(32, 16, 4) \
-    X(64, 8, 1) X(64, 16, 1) X(64, 16, 2) X(64, 16, 4) X(64, 16, 8)
+    X(64, 8, 1) X(64, 16, 1) X(64, 16, 2) X(64, 16, 4) X(64, 25, 4) X(64, 16, 8)
 
 bool pick_variant(uint32_t emb_dim, uint32_t num_negs, int* lpr_out, int* ng_out, int* nw_out)
 {
