@@ -105,9 +105,17 @@ __device__ __forceinline__ void flush_user_row(const TrainArgs& a, uint32_t user
 // [w*NGW*R, (w+1)*NGW*R); user and positive rows are replicated in every wave's registers (every wave computes the
 // identical update of them, wave 0 writes them back).  Softmax statistics and the user-gradient partial sums cross
 // waves through LDS (2-3 workgroup barriers per interaction).  NW = 1 compiles all of that away.
-template <int LPR, int NGW, int AUX, int NW>
+//
+// AGG = true adds the reference's behaviour aggregation (behavior_aggregators/behavior_aggregators.cpp:51-153, called
+// unconditionally at matrix_factorization.cpp:38,152): u <- 0.4 u + 0.6 (mean of the user's history item rows) W0, in
+// place, before the dots; after the negative sweep the W0 gradient means (x) (0.6 g_u) is accumulated per stream and
+// applied every 32 calls (W0 -= lr * acc/32, here by float atomic adds on the shared W0), and g_u *= 0.4.
+// The stream keeps a private LDS copy of W0 (refreshed after each of its own W0 updates) and the last <= 32
+// (means, 0.6 g_u) pairs; the accumulation order of the reference (call by call) is preserved when the pairs are summed.
+template <int LPR, int NGW, int AUX, int NW, bool AGG>
 __global__ __launch_bounds__(64 * NW) void ccl_train_kernel(TrainArgs a)
 {
+    static_assert(!AGG || NW == 1, "behaviour aggregation is built for single-wave workgroups");
     const bool neg_w_atomic = (a.upd_bits & 1u) != 0u, neg_g_atomic = (a.upd_bits & 2u) != 0u;
     const bool pos_w_atomic = (a.upd_bits & 4u) != 0u, pos_g_atomic = (a.upd_bits & 8u) != 0u;
     const bool any_atomic = a.upd_bits != 0u;
@@ -144,6 +152,22 @@ __global__ __launch_bounds__(64 * NW) void ccl_train_kernel(TrainArgs a)
     __shared__ __attribute__((aligned(16))) float sh_gu[NW > 1 ? NW * 64 * 4 : 4]; // per-wave user-gradient partials
     __shared__ float sh_slg[NW > 1 ? NW : 1];
     float* tile = tile_all + wave * 256;
+    // aggregation state (dynamic LDS: W0 copy [D*D] | pair ring [32][2][DP] | means [DP]); D = emb_dim, DP = 4*LPR
+    extern __shared__ __attribute__((aligned(16))) float agg_lds[];
+    constexpr int DP = 4 * LPR;
+    const int D = (int)a.emb_dim;
+    float* agg_w0 = agg_lds;
+    float* agg_pairs = agg_lds + (AGG ? D * D : 0);
+    float* agg_means = agg_pairs + (AGG ? 32 * 2 * DP : 0);
+    uint32_t agg_iter = 0u;                 // behavior_aggregators.cpp:31 (per worker, per epoch)
+    uint32_t agg_H = 0u;
+    uint32_t hid[2] = {0u, 0u};             // history ids of the current user: lane l holds his[l], his[64 + l]
+    f32x4 means4 = {0, 0, 0, 0};
+    if (AGG)
+    {
+        for (int t = lane; t < D * D / 4; t += 64)   // W0 is [D,D] row-major, D % 4 == 0
+            reinterpret_cast<f32x4*>(agg_w0)[t] = buf_load<AUX>(make_rsrc(a.w0, (uint32_t)(D * D * 4)), (uint32_t)t * 16u);
+    }
     // A user run cut by a stream boundary is also being updated by the neighbouring stream: its row is then written
     // back as an atomic delta (nothing lost); a run owned entirely by this stream is written back with plain stores.
     uint32_t cut_head_user = 0xFFFFFFFFu, cut_tail_user = 0xFFFFFFFFu;
@@ -195,7 +219,13 @@ __global__ __launch_bounds__(64 * NW) void ccl_train_kernel(TrainArgs a)
                 }
                 else
                 {
-                    id = uniform_item(philox_draw64(slot, a.sample_base + idx, a.key), a.num_items);
+                    // the tile sampler's ignore_pos_sampling() does not use the tile
+                    // (random_tile_negative_sampler.cpp:47-57), only its sampling() does (:23-45)
+                    if (a.tile_size != 0u && a.sampling_call)
+                        id = tile_item(slot, a.sample_base + idx, a.key, blockIdx.x, idx - first, a.tile_size,
+                                       a.refresh_interval, a.num_items);
+                    else
+                        id = uniform_item(philox_draw64(slot, a.sample_base + idx, a.key), a.num_items);
                     // ignore_pos_sampling (uniform_random_negative_sampler.cpp:26-36): a draw equal to the
                     // positive leaves the slot unchanged (previous interaction's id, initially 0)
                     if (!a.sampling_call && id == pos) id = nid[v];
@@ -218,6 +248,53 @@ __global__ __launch_bounds__(64 * NW) void ccl_train_kernel(TrainArgs a)
                 gu4 = buf_load<AUX>(make_rsrc((const char*)a.user_g + o, a.row_bytes), uo);
                 u4_in = u4;
                 gu4_in = gu4;
+                if (AGG)
+                {
+                    agg_H = a.masks[user];                                        // behavior_aggregators.cpp:61-62
+                    const uint32_t* hrow = a.his + (size_t)user * a.max_his;       // :60
+                    hid[0] = (uint32_t)lane < agg_H ? hrow[lane] : 0u;
+                    hid[1] = (uint32_t)(64 + lane) < agg_H ? hrow[64 + lane] : 0u;
+                }
+            }
+            if (AGG)
+            {
+                // ---- aggregator forward (behavior_aggregators.cpp:96-122) -----------------------------------------
+                f32x4 hs = {0, 0, 0, 0};
+                for (uint32_t h0 = 0; h0 < agg_H; h0 += (uint32_t)(R * 8))
+                {
+                    f32x4 part[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q)
+                    {
+                        const uint32_t hh = h0 + (uint32_t)(q * R + rr);
+                        const uint32_t id0 = lane_get(hid[0], (int)(hh & 63u));
+                        const uint32_t id1 = lane_get(hid[1], (int)(hh & 63u));
+                        const uint32_t id = hh < 64u ? id0 : id1;
+                        part[q] = buf_load<AUX>(item_w, (hh < agg_H && col_ok) ? id * a.row_bytes + col_off : OOB_OFF);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) hs += part[q];
+                }
+                hs.x = cross_sum<LPR>(hs.x);
+                hs.y = cross_sum<LPR>(hs.y);
+                hs.z = cross_sum<LPR>(hs.z);
+                hs.w = cross_sum<LPR>(hs.w);
+                means4 = hs * (1.0f / (float)agg_H);                                  // :63,105
+                if (rr == 0) *reinterpret_cast<f32x4*>(agg_means + sub * 4) = means4;
+                f32x4 f4 = {0, 0, 0, 0};
+                for (int i = rr; i < D; i += R)                                       // :118 f = means (1xD) * W0 (DxD)
+                {
+                    const float m = agg_means[i];
+                    const f32x4 wrow = col_ok ? *reinterpret_cast<const f32x4*>(agg_w0 + i * D + sub * 4) : f32x4{0, 0, 0, 0};
+                    f4 += m * wrow;
+                }
+                f4.x = cross_sum<LPR>(f4.x);
+                f4.y = cross_sum<LPR>(f4.y);
+                f4.z = cross_sum<LPR>(f4.z);
+                f4.w = cross_sum<LPR>(f4.w);
+                const float gamma = 0.4f, omg = 1.0f - gamma;                          // :37, :122
+                u4 = gamma * u4 + omg * f4;
+                agg_iter += 1u;                                                       // :124
             }
 
             // ---- gather: positive row (replicated in every row group) + this wave's negative rows (W only; the
@@ -422,7 +499,46 @@ __global__ __launch_bounds__(64 * NW) void ccl_train_kernel(TrainArgs a)
                 }
             }
 
-            gu4 = clip4(gu4 + gu_acc, clip);                                    // :166
+            if (AGG)
+            {
+                // ---- aggregator backward (behavior_aggregators.cpp:129-153) ----------------------------------------
+                const float gamma = 0.4f, omg = 1.0f - gamma;
+                const f32x4 gfull = gu4 + gu_acc;                                    // outs_grad = persistent G + this step
+                const f32x4 fgrad = gfull * omg;                                     // :132
+                const uint32_t slot32 = (agg_iter - 1u) & 31u;
+                if (rr == 0)
+                {
+                    *reinterpret_cast<f32x4*>(agg_pairs + (slot32 * 2 + 0) * DP + sub * 4) = means4;
+                    *reinterpret_cast<f32x4*>(agg_pairs + (slot32 * 2 + 1) * DP + sub * 4) = fgrad;
+                }
+                if ((agg_iter & 31u) == 0u)                                          // :141 (iteration > 0 holds here)
+                {
+                    const __amdgpu_buffer_rsrc_t w0r = make_rsrc(a.w0, (uint32_t)(D * D * 4));
+                    for (int i0 = 0; i0 < D; i0 += R)                                // R rows of W0 per tile
+                    {
+                        const int i = i0 + rr;
+                        f32x4 acc = {0, 0, 0, 0};
+                        for (int c = 0; c < 32; ++c)                                 // :134-139 in call order
+                        {
+                            const float m = agg_pairs[(c * 2 + 0) * DP + (i < D ? i : 0)];
+                            const f32x4 fg = *reinterpret_cast<const f32x4*>(agg_pairs + (c * 2 + 1) * DP + sub * 4);
+                            acc += m * fg;
+                        }
+                        const f32x4 delta = -(a.agg_lr * (acc / 32.0f));             // :143-144
+                        const uint32_t off = (i < D && col_ok) ? (uint32_t)(i * D * 4) + col_off : OOB_OFF;
+                        const AtomicOffsets ao = atomic_offsets(off, lane);
+                        atomic_add_tile<4>(w0r, ao, delta, tile, lane);
+                    }
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // own W0 updates performed ...
+                    for (int t = lane; t < D * D / 4; t += 64)                       // ... then refresh the private copy
+                        reinterpret_cast<f32x4*>(agg_w0)[t] = buf_load<AUX>(w0r, (uint32_t)t * 16u);
+                }
+                gu4 = clip4(gfull * gamma, clip);                                    // :148-152 then sgd.cpp:22
+            }
+            else
+            {
+                gu4 = clip4(gu4 + gu_acc, clip);                                     // :166
+            }
             u4 = u4 - lr * gu4;
             const f32x4 gp_old = gp4;
             gp4 = clip4(gp4 + slg * upp, clip);                                 // :169
@@ -499,7 +615,12 @@ __global__ __launch_bounds__(64) void sample_negs_kernel(TrainArgs a, uint64_t o
         for (int v = 0; v < nidv && v < 4; ++v)
         {
             const uint32_t slot = (uint32_t)(v * 64 + lane);
-            uint32_t id = uniform_item(philox_draw64(slot, a.sample_base + idx, a.key), a.num_items);
+            uint32_t id;
+            if (a.tile_size != 0u && a.sampling_call)
+                id = tile_item(slot, a.sample_base + idx, a.key, blockIdx.x, idx - first, a.tile_size, a.refresh_interval,
+                               a.num_items);
+            else
+                id = uniform_item(philox_draw64(slot, a.sample_base + idx, a.key), a.num_items);
             if (!a.sampling_call && id == pos) id = prev[v];
             prev[v] = id;
             if (slot < N) out[(idx - out_base) * N + slot] = (uint64_t)id;
@@ -511,10 +632,27 @@ __global__ __launch_bounds__(64) void sample_negs_kernel(TrainArgs a, uint64_t o
 template <int LPR, int NGW, int NW>
 static hipError_t launch_variant(const TrainArgs& a, uint32_t grid, int aux, hipStream_t s)
 {
+    if (a.agg)
+    {
+        if constexpr (NW == 1)
+        {
+            if (aux != AUX_SC1) return hipErrorInvalidValue;
+            const size_t lds = ((size_t)a.emb_dim * a.emb_dim + 32 * 2 * 4 * LPR + 4 * LPR) * sizeof(float);
+            auto kern = ccl_train_kernel<LPR, NGW, AUX_SC1, 1, true>;
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(64), lds, s, a);
+            return hipGetLastError();
+        }
+        else
+        {
+            return hipErrorInvalidValue;
+        }
+    }
     if (aux == AUX_PLAIN)
-        hipLaunchKernelGGL((ccl_train_kernel<LPR, NGW, AUX_PLAIN, NW>), dim3(grid), dim3(64 * NW), 0, s, a);
+        hipLaunchKernelGGL((ccl_train_kernel<LPR, NGW, AUX_PLAIN, NW, false>), dim3(grid), dim3(64 * NW), 0, s, a);
     else
-        hipLaunchKernelGGL((ccl_train_kernel<LPR, NGW, AUX_SC1, NW>), dim3(grid), dim3(64 * NW), 0, s, a);
+        hipLaunchKernelGGL((ccl_train_kernel<LPR, NGW, AUX_SC1, NW, false>), dim3(grid), dim3(64 * NW), 0, s, a);
     return hipGetLastError();
 }
 

@@ -19,6 +19,8 @@ struct TrainArgs
     uint32_t     num_items, num_negs, emb_dim, row_bytes;
     uint32_t     item_bytes; // num_items * row_bytes (< 4 GiB: 32-bit buffer offsets)
     uint32_t     sampling_call;
+    uint32_t     tile_size;  // 0: uniform sampler; >0: random-tile sampler (used by the sampling() call only)
+    uint32_t     refresh_interval;
     uint32_t     upd_bits;   // bit0 neg W atomic, bit1 neg G atomic, bit2 pos W atomic, bit3 pos G atomic
     uint32_t     align_cap;  // how far a stream boundary may move forward to the next user-run start
     float        lr, clip;
@@ -29,6 +31,13 @@ struct TrainArgs
     uint32_t*    neg_out;     // optional record of the negatives used, row (idx - neg_out_base)
     uint64_t     neg_out_base;
     double*      loss_part;   // [grid] per-stream loss sums
+    // behaviour aggregation (use_aggregator)
+    uint32_t        agg;      // 0 / 1
+    uint32_t        max_his;
+    const uint32_t* his;      // [num_users, max_his] packed u32 history item ids
+    const uint32_t* masks;    // [num_users] history lengths
+    float*          w0;       // [emb_dim, emb_dim] shared aggregator weights
+    float           agg_lr;   // frozen at the CONFIG learning rate (behavior_aggregators.cpp:38)
 };
 
 // per-epoch sampler key: (seed, epoch) -> 64-bit Philox key (= the `seed` argument of hiprand_init)

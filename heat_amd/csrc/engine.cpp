@@ -63,6 +63,9 @@ struct heat_cf_engine
     float*   d_user_g = nullptr;
     float*   d_item_g = nullptr;
     float*   d_w0 = nullptr;
+    uint32_t* d_his = nullptr;
+    uint32_t* d_masks = nullptr;
+    uint64_t  max_his = 0;
     bool     own_tables = false;
     uint64_t data_rows = 0;
     // scratch
@@ -106,8 +109,9 @@ int validate_cfg(const heat_cf_config* cfg, uint64_t data_rows, int* lpr, int* n
         return fail(HEAT_CF_EINVAL, "milestones must hold at least one epoch (engine.cpp:159 reads milestones[0])");
     if (cfg->n_milestones == 1 && cfg->milestones[0] == 0)
         return fail(HEAT_CF_EINVAL, "milestones[0] must be > 0 (optimizer.cpp:26 computes epoch % step_size)");
-    if (cfg->use_aggregator) return fail(HEAT_CF_EUNSUP, "behaviour aggregation (ACCL) is not built yet");
     if (cfg->neg_sampler != 0 && cfg->neg_sampler != 1) return fail(HEAT_CF_EINVAL, "neg_sampler must be 0 or 1");
+    if (cfg->neg_sampler == 1 && (cfg->tile_size == 0 || cfg->tile_size > 0xFFFFFFFFull || cfg->refresh_interval == 0))
+        return fail(HEAT_CF_EINVAL, "random-tile sampler needs tile_size > 0 and refresh_interval > 0");
     if (!pick_variant((uint32_t)cfg->emb_dim, (uint32_t)cfg->num_negs, lpr, ng, nw))
         return fail(HEAT_CF_EUNSUP, "no compiled kernel variant for this (emb_dim, num_negs)");
     if (data_rows >= (1ull << 40)) return fail(HEAT_CF_EINVAL, "data_rows too large");
@@ -165,6 +169,12 @@ int common_init(heat_cf_engine* e, const heat_cf_config* cfg, uint64_t data_rows
         (void)lpr;
         uint64_t fill = (uint64_t)e->cu_count * 4ull * waves_per_simd / (uint64_t)e->nw;   // workgroups (= streams)
         if (fill < e->cu_count) fill = e->cu_count;
+        if (cfg->use_aggregator)
+        {
+            const uint64_t lds = (cfg->emb_dim * cfg->emb_dim + 32 * 2 * 4 * (uint64_t)lpr + 4 * (uint64_t)lpr) * 4 + 1024;
+            const uint64_t per_cu = std::max<uint64_t>(1, (160 * 1024) / lds);
+            fill = std::min<uint64_t>(fill, (uint64_t)e->cu_count * per_cu);
+        }
         const uint64_t cap_items = (uint64_t)(0.033 * (double)cfg->num_items);
         const uint64_t cap_users = (uint64_t)(0.058 * (double)cfg->num_users);
         uint64_t streams = std::min(fill, std::min(cap_items, cap_users));
@@ -270,6 +280,8 @@ TrainArgs make_args(const heat_cf_engine* e, uint64_t begin, uint64_t end)
     a.row_bytes = (uint32_t)e->cfg.emb_dim * 4u;
     a.item_bytes = (uint32_t)(e->cfg.num_items * e->cfg.emb_dim * 4ull);
     a.sampling_call = (e->cfg.flags & HEAT_CF_FLAG_SAMPLING_CALL) ? 1u : 0u;
+    a.tile_size = e->cfg.neg_sampler == 1 ? (uint32_t)e->cfg.tile_size : 0u;
+    a.refresh_interval = (uint32_t)std::max<uint64_t>(1, e->cfg.refresh_interval);
     a.upd_bits = (uint32_t)e->upd;
     a.align_cap = e->upd == 0 ? 4096u : 0u; // overwrite mode keeps a user's run inside one stream; atomic modes need not
     a.lr = e->lr;
@@ -279,6 +291,12 @@ TrainArgs make_args(const heat_cf_engine* e, uint64_t begin, uint64_t end)
     a.ext_negs = nullptr;
     a.neg_out = nullptr;
     a.loss_part = e->d_loss_part;
+    a.agg = e->cfg.use_aggregator ? 1u : 0u;
+    a.max_his = (uint32_t)e->max_his;
+    a.his = e->d_his;
+    a.masks = e->d_masks;
+    a.w0 = e->d_w0;
+    a.agg_lr = e->cfg.l_r; // behavior_aggregators.cpp:38: frozen at the config value, not the scheduled lr
     return a;
 }
 
@@ -294,6 +312,8 @@ void destroy_impl(heat_cf_engine* e)
         (void)hipFree(e->d_item_w);
         (void)hipFree(e->d_w0);
     }
+    (void)hipFree(e->d_his);
+    (void)hipFree(e->d_masks);
     (void)hipFree(e->d_user_g);
     (void)hipFree(e->d_item_g);
     (void)hipFree(e->d_clicks);
@@ -324,13 +344,40 @@ int heat_cf_engine_create(const heat_cf_config* cfg, const uint64_t* clicks, uin
                           uint64_t max_his, const uint64_t* masks, float* user_w, float* item_w, float* w0,
                           heat_cf_engine** out)
 {
-    (void)his; (void)max_his; (void)masks;
     if (!out) return fail(HEAT_CF_EINVAL, "out is NULL");
     *out = nullptr;
     int lpr = 0, ng = 0, nw = 1;
     int rc = validate_cfg(cfg, data_rows, &lpr, &ng, &nw);
     if (rc) return rc;
     if (!clicks && data_rows) return fail(HEAT_CF_EINVAL, "clicks is NULL");
+    std::vector<uint32_t> his32, masks32;
+    if (cfg->use_aggregator)
+    {
+        if (!his || !masks || !w0) return fail(HEAT_CF_EINVAL, "use_aggregator needs historical_items, masks and aggregator weights");
+        if (nw != 1) return fail(HEAT_CF_EUNSUP, "behaviour aggregation is built for single-wave variants (num_negs <= 64 rows per wave)");
+        if (max_his == 0 || max_his > 128) return fail(HEAT_CF_EUNSUP, "behaviour aggregation supports 1 <= max_his <= 128");
+        if ((cfg->emb_dim * cfg->emb_dim + 32 * 2 * 4 * (uint64_t)lpr + 4 * (uint64_t)lpr) * 4 > 160 * 1024)
+            return fail(HEAT_CF_EUNSUP, "behaviour aggregation keeps W0 in LDS: emb_dim too large");
+        try { his32.resize(cfg->num_users * max_his); masks32.resize(cfg->num_users); }
+        catch (const std::bad_alloc&) { return fail(HEAT_CF_ENOMEM, "host allocation failed"); }
+        for (uint64_t u = 0; u < cfg->num_users; ++u)
+        {
+            const uint64_t h = masks[u];
+            if (h > max_his) return fail(HEAT_CF_EINVAL, "masks[" + std::to_string(u) + "] exceeds max_his");
+            masks32[u] = (uint32_t)h;
+            for (uint64_t k = 0; k < max_his; ++k)
+            {
+                const uint64_t it = his[u * max_his + k];
+                if (k < h && it >= cfg->num_items) return fail(HEAT_CF_EINVAL, "historical_items holds an id out of range");
+                his32[u * max_his + k] = k < h ? (uint32_t)it : 0u;
+            }
+        }
+        // behavior_aggregators.cpp:63 divides by masks[u]: a user with interactions but an empty history would poison
+        // its row with inf/NaN (the reference's datasets never produce one, README.md:83-86)
+        for (uint64_t i = 0; i < data_rows; ++i)
+            if (clicks[2 * i] < cfg->num_users && masks32[clicks[2 * i]] == 0)
+                return fail(HEAT_CF_EINVAL, "user " + std::to_string(clicks[2 * i]) + " has interactions but masks == 0");
+    }
     if (!user_w || !item_w) return fail(HEAT_CF_EINVAL, "user_w / item_w is NULL");
     // range check + pack to u32 pairs (the reference performs no bounds checks; on a GPU an out-of-range id
     // is a memory fault, so it is rejected here)
@@ -377,6 +424,17 @@ int heat_cf_engine_create(const heat_cf_config* cfg, const uint64_t* clicks, uin
         // embeddings/embedding.cpp:12-13 + memory/array.hpp:22-24: owned, zero-initialised gradient tables
         HIP_TRY(hipMemsetAsync(e->d_user_g, 0, user_bytes(e), e->stream));
         HIP_TRY(hipMemsetAsync(e->d_item_g, 0, item_bytes(e), e->stream));
+        if (cfg->use_aggregator)
+        {
+            e->max_his = max_his;
+            const size_t w0b = (size_t)cfg->emb_dim * cfg->emb_dim * sizeof(float);
+            HIP_TRY(hipMalloc(&e->d_w0, w0b));
+            HIP_TRY(hipMalloc(&e->d_his, his32.size() * sizeof(uint32_t)));
+            HIP_TRY(hipMalloc(&e->d_masks, masks32.size() * sizeof(uint32_t)));
+            HIP_TRY(hipMemcpyAsync(e->d_w0, w0, w0b, hipMemcpyHostToDevice, e->stream));
+            HIP_TRY(hipMemcpyAsync(e->d_his, his32.data(), his32.size() * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
+            HIP_TRY(hipMemcpyAsync(e->d_masks, masks32.data(), masks32.size() * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
+        }
         HIP_TRY(hipStreamSynchronize(e->stream));
         return HEAT_CF_OK;
     };
@@ -397,6 +455,7 @@ int heat_cf_engine_create_device(const heat_cf_config* cfg, const void* d_clicks
     if (rc) return rc;
     if (!d_clicks && data_rows) return fail(HEAT_CF_EINVAL, "d_clicks is NULL");
     if (!d_user_w || !d_item_w) return fail(HEAT_CF_EINVAL, "d_user_w / d_item_w is NULL");
+    if (cfg->use_aggregator) return fail(HEAT_CF_EUNSUP, "behaviour aggregation is available in host mode only");
     if (((uintptr_t)d_user_w | (uintptr_t)d_item_w) & 15u) return fail(HEAT_CF_EINVAL, "tables must be 16-byte aligned");
     heat_cf_engine* e = new (std::nothrow) heat_cf_engine();
     if (!e) return fail(HEAT_CF_ENOMEM, "host allocation failed");
@@ -667,6 +726,8 @@ int heat_cf_sync_to_host(heat_cf_engine* e)
     HIP_TRY(hipSetDevice(e->device));
     HIP_TRY(hipMemcpyAsync(e->h_user_w, e->d_user_w, user_bytes(e), hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipMemcpyAsync(e->h_item_w, e->d_item_w, item_bytes(e), hipMemcpyDeviceToHost, e->stream));
+    if (e->cfg.use_aggregator && e->h_w0 && e->d_w0)
+        HIP_TRY(hipMemcpyAsync(e->h_w0, e->d_w0, (size_t)e->cfg.emb_dim * e->cfg.emb_dim * sizeof(float), hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
     return HEAT_CF_OK;
 }
@@ -678,6 +739,8 @@ int heat_cf_sync_from_host(heat_cf_engine* e)
     HIP_TRY(hipSetDevice(e->device));
     HIP_TRY(hipMemcpyAsync(e->d_user_w, e->h_user_w, user_bytes(e), hipMemcpyHostToDevice, e->stream));
     HIP_TRY(hipMemcpyAsync(e->d_item_w, e->h_item_w, item_bytes(e), hipMemcpyHostToDevice, e->stream));
+    if (e->cfg.use_aggregator && e->h_w0 && e->d_w0)
+        HIP_TRY(hipMemcpyAsync(e->d_w0, e->h_w0, (size_t)e->cfg.emb_dim * e->cfg.emb_dim * sizeof(float), hipMemcpyHostToDevice, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
     return HEAT_CF_OK;
 }

@@ -62,3 +62,33 @@ def negatives(clicks, begin, end, num_negs, num_items, key, per_block, sample_ba
         out[r] = np.where(hit, prev, raw[r])
         prev = out[r]
     return out
+
+
+def _mulhi64(draws, n):
+    return np.array([(int(d) * int(n)) >> 64 for d in draws], dtype=np.uint64)
+
+
+def _draw64(slot, idx, key):
+    slot = np.asarray(slot, dtype=np.uint32)
+    idx = np.asarray(idx, dtype=np.uint64)
+    k0 = np.full(slot.shape, key & 0xFFFFFFFF, dtype=np.uint32)
+    k1 = np.full(slot.shape, key >> 32, dtype=np.uint32)
+    x, y, _, _ = philox4x32_10(slot, np.zeros_like(slot), (idx & MASK).astype(np.uint32),
+                               (idx >> np.uint64(32)).astype(np.uint32), k0, k1)
+    return [(int(a) | (int(b) << 32)) for a, b in zip(x.tolist(), y.tolist())]
+
+
+def tile_negatives(begin, end, num_negs, num_items, key, tile_size, refresh_interval, per_block, sample_base=0):
+    """sampling() of the random-tile sampler as the kernel computes it (ccl_device.hpp: tile_item), one stream per
+    `per_block` interactions: tile index j from the per-interaction draw, tile entry from the (stream, tile_epoch) domain."""
+    n = end - begin
+    idx = np.repeat(np.arange(begin, end, dtype=np.uint64) + np.uint64(sample_base), num_negs)
+    slot = np.tile(np.arange(num_negs, dtype=np.uint32), n)
+    j = _mulhi64(_draw64(slot, idx, key), tile_size)
+    rel = np.repeat(np.arange(n, dtype=np.uint64), num_negs)
+    stream = rel // np.uint64(per_block)
+    call = rel % np.uint64(per_block)
+    tile_epoch = call // np.uint64(refresh_interval)
+    tidx = (np.uint64(1) << np.uint64(63)) | (stream << np.uint64(32)) | tile_epoch
+    ids = _mulhi64(_draw64(j.astype(np.uint32), tidx, key), num_items)
+    return ids.reshape(n, num_negs)

@@ -98,6 +98,36 @@ def test_reference_hyperparameters_short_horizon():
     assert_tables_close(ig, io, scale=np.abs(io).max(), rtol=5e-4)
 
 
+@pytest.mark.parametrize("d,N,H", [(64, 16, 100), (64, 4, 7), (128, 16, 40), (32, 8, 100)])
+def test_aggregator_serial_walk_matches_oracle(d, N, H):
+    """ACCL mode (behavior_aggregators.cpp:51-153): history mean -> W0 -> in-place blend of the user row, W0 gradient
+    accumulated per worker and applied every 32 calls.  Serial GPU walk vs the oracle, crossing several W0 updates."""
+    U, I, T = 12, 400, 200
+    rng = np.random.default_rng(d + N + H)
+    clicks = np.stack([np.sort(rng.integers(0, U, T)), rng.integers(0, I, T)], axis=1).astype(np.uint64)
+    uw = (rng.standard_normal((U, d)) * 0.1).astype(np.float32)
+    iw = (rng.standard_normal((I, d)) * 0.1).astype(np.float32)
+    w0 = (rng.standard_normal((d, d)) * 0.1).astype(np.float32)
+    his = rng.integers(0, I, size=(U, H)).astype(np.uint64)
+    masks = rng.integers(1, H + 1, size=(U, 1)).astype(np.uint64)
+    masks[0, 0] = H                                             # one user with a full history
+    negs = rng.integers(0, I, size=(T, N)).astype(np.uint64)
+    ug, ig, wg = uw.copy(), iw.copy(), w0.copy()
+    uo, io, wo = uw.copy(), iw.copy(), w0.copy()
+    eng = abi.Engine(clicks, ug, ig, num_negs=N, his=his, masks=masks, w0=wg, use_aggregator=True, flags=abi.FLAG_SERIAL,
+                     l_r=0.01, clip_val=1.0)
+    ora = orc.Engine(clicks, uo, io, num_negs=N, his=his, masks=masks, w0=wo, use_aggregator=True, l_r=0.01, clip_val=1.0)
+    lg = eng.train_range(0, T, negs)
+    lo = ora.train_range(0, T, negs)
+    eng.sync_to_host()
+    eng.close()
+    assert abs(lg - lo) <= 1e-5 * abs(lo)
+    assert not np.array_equal(wo, w0)                           # W0 moved (T/32 updates)
+    assert_tables_close(wg, wo, scale=np.abs(wo).max(), rtol=1e-4)
+    assert_tables_close(ug, uo, scale=np.abs(uo).max(), rtol=5e-4)
+    assert_tables_close(ig, io, scale=np.abs(io).max(), rtol=5e-4)
+
+
 def test_sampler_is_philox_bit_exact():
     d, N, U, I, T = 64, 16, 50, 1000, 2000
     clicks, uw, iw = small_problem(U, I, T, d, seed=9)
@@ -128,6 +158,30 @@ def test_sampler_ignore_pos_keeps_previous_slot():
     raw = philox_ref.raw_negatives(np.arange(T, dtype=np.uint64), N, 3, philox_ref.epoch_key(7, 0))
     assert (raw == clicks[:, 1:2]).mean() > 0.2  # the rule was exercised
     eng.close()
+
+
+def test_random_tile_sampler_bit_exact_and_tile_bounded():
+    """neg_sampler=1 with the sampling() call (engine.cpp:333 variant): ids equal the numpy restatement, and inside one
+    refresh window a stream draws from at most tile_size distinct items (random_tile_negative_sampler.cpp:23-45)."""
+    d, N, U, I, T = 64, 16, 50, 5000, 700
+    clicks, uw, iw = small_problem(U, I, T, d, seed=9)
+    eng = abi.Engine(clicks, uw, iw, num_negs=N, seed=11, neg_sampler=1, tile_size=32, refresh_interval=100,
+                     flags=abi.FLAG_SERIAL | abi.FLAG_SAMPLING_CALL)
+    got = eng.sample_negatives(0, T)
+    want = philox_ref.tile_negatives(0, T, N, I, philox_ref.epoch_key(11, 0), 32, 100, per_block=((T + 63) // 64) * 64)
+    assert np.array_equal(got, want)
+    for w in range(0, T, 100):
+        assert np.unique(got[w:w + 100]).size <= 32
+    assert np.unique(got).size > 32 * 3          # the tile was refreshed
+    # ignore_pos_sampling of the tile sampler does not use the tile (random_tile_negative_sampler.cpp:47-57)
+    eng2 = abi.Engine(clicks, uw, iw, num_negs=N, seed=11, neg_sampler=1, tile_size=32, refresh_interval=100,
+                      flags=abi.FLAG_SERIAL)
+    uni = abi.Engine(clicks, uw, iw, num_negs=N, seed=11, flags=abi.FLAG_SERIAL)
+    assert np.array_equal(eng2.sample_negatives(0, T), uni.sample_negatives(0, T))
+    loss = eng.train_range(0, T)                  # and it trains
+    assert np.isfinite(loss)
+    for e in (eng, eng2, uni):
+        e.close()
 
 
 def test_gpu_sampler_drives_training_like_fed_negatives():
