@@ -187,3 +187,26 @@ def make_clicks_torch(num_users, num_items, n, device, seed=2022, zipf_s=1.0):
     items = perm[torch.searchsorted(cdf, r).clamp_(0, num_items - 1)]
     del r, cdf, ranks
     return torch.stack([users, items], dim=1).contiguous()
+
+
+def make_history(graph, max_his=100, seed=2022):
+    """historical_items [num_users, max_his] u64 and masks [num_users, 1] u64 as cf/datasets.py:58-72 builds them:
+    a user with >= max_his train items gets a random sample of max_his of them, otherwise its items padded with the
+    last one; masks = min(len, max_his).  Vectorised (numpy Generator instead of random.sample)."""
+    rng = np.random.default_rng(seed)
+    U = graph.num_users
+    tp = graph.train_indptr.astype(np.int64)
+    items = graph.train_items.astype(np.uint64)
+    his = np.zeros((U, max_his), dtype=np.uint64)
+    masks = np.zeros((U, 1), dtype=np.uint64)
+    for u in range(U):
+        row = items[tp[u]:tp[u + 1]]
+        n = row.size
+        if n >= max_his:
+            his[u] = rng.choice(row, size=max_his, replace=False)
+            masks[u, 0] = max_his
+        elif n > 0:
+            his[u, :n] = row
+            his[u, n:] = row[-1]
+            masks[u, 0] = n
+    return his, masks

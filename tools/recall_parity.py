@@ -25,6 +25,7 @@ ap.add_argument("--clip", type=float, default=1.0)
 ap.add_argument("--seeds", type=str, default="2022")
 ap.add_argument("--clusters", type=int, default=0)
 ap.add_argument("--lr", type=float, default=0.01)
+ap.add_argument("--agg", action="store_true", help="behaviour aggregation (ACCL) on both sides")
 args = ap.parse_args()
 
 g, d, N = synthetic.make_named(args.shape, scale=args.scale, n_clusters=args.clusters)
@@ -49,23 +50,31 @@ def evaluate(uw, iw, tag):
     return r
 
 
+his = masks = None
+if args.agg:
+    his, masks = synthetic.make_history(g, 100, seed=2022)
 for seed in [int(x) for x in args.seeds.split(",")]:
     uw0, iw0 = synthetic.init_embeddings(g.num_users, g.num_items, d, seed=seed)
+    w00 = (np.random.default_rng(seed).standard_normal((d, d)) * 0.01).astype(np.float32)
     for coh, upd in [(int(c), int(u)) for c in args.coherence.split(",") for u in args.update.split(",")]:
         for streams in [int(x) for x in args.streams.split(",")]:
             uw, iw = uw0.copy(), iw0.copy()
-            eng = abi.Engine(g.clicks, uw, iw, num_negs=N, seed=seed, coherence=coh, num_streams=streams, clip_val=args.clip, l_r=args.lr,
+            agg_kw = dict(his=his, masks=masks, w0=w00.copy(), use_aggregator=True) if args.agg else {}
+            eng = abi.Engine(g.clicks, uw, iw, num_negs=N, seed=seed, **agg_kw, coherence=coh, num_streams=streams, clip_val=args.clip, l_r=args.lr,
                              flags=abi.FLAG_LAZY_SYNC, update_mode=upd)
             t0 = time.time()
             losses = [eng.train_one_epoch() for _ in range(args.epochs)]
             dt = time.time() - t0
             eng.sync_to_host()
+            kms, kn = eng.kernel_time()
+            print(f"  kernel {kms / max(kn, 1):.3f} ms/epoch")
+            print(f"GPU seed={seed} coherence={coh} update={upd} {eng.kernel_name} streams={streams}: losses={[round(x, 4) for x in losses]} ({dt:.2f}s)", flush=True)
             eng.close()
-            print(f"GPU seed={seed} coherence={coh} update={upd} {eng.kernel_name if False else ''} streams={streams}: losses={[round(x, 4) for x in losses]} ({dt:.2f}s)", flush=True)
             evaluate(uw, iw, f"gpu coh={coh} upd={upd} streams={streams}")
     for th in [int(x) for x in args.oracle_threads.split(",")]:
         uo, io = uw0.copy(), iw0.copy()
-        ora = orc.Engine(g.clicks, uo, io, num_negs=N, clip_val=args.clip, l_r=args.lr)
+        agg_kw = dict(his=his, masks=masks, w0=w00.copy(), use_aggregator=True) if args.agg else {}
+        ora = orc.Engine(g.clicks, uo, io, num_negs=N, clip_val=args.clip, l_r=args.lr, **agg_kw)
         t0 = time.time()
         losses = [ora.train_one_epoch(num_threads=th) for _ in range(args.epochs)]
         dt = time.time() - t0
