@@ -74,7 +74,7 @@ def main():
     abi.load()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:
         dist.init_process_group("nccl", device_id=dev)
 
     U, I, T, d, N = synthetic.SHAPES[args.shape]
@@ -101,7 +101,7 @@ def main():
                                  emb_dim=d, num_negs=N, stream=stream, keep=(clicks, user_w, item_w), seed=2022,
                                  sample_index_base=rank * T, update_mode=args.update_mode, device=local_rank)
     trainer = None
-    if world > 1:
+    if world > 1 or os.environ.get("HEAT_BENCH_FORCE_SYNC"):   # the env switch exercises the N>1 code path on one GPU
         from heat_amd.cf.distributed import ItemSync
         trainer = ItemSync(eng, item_w, world, refresh_interval=8192, sync_interactions=args.sync_interactions)
 
@@ -114,7 +114,7 @@ def main():
             trainer.train_one_epoch()
 
     def fence():
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -176,7 +176,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(graph, d, N)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
     eng.close()

@@ -52,8 +52,10 @@ class ClickDataset(Dataset):
             item_ids.update(items)
             pairs.extend((user_id, it) for it in items)          # :74-78 interactions in file order
         self.user_item_ids = pairs
-        self.num_users = len(self.user_items_dic)
-        self.num_items = len(item_ids)
+        # datasets.py:96-97 count distinct ids and assume they are 0..n-1; sparse id spaces (an item that never occurs in
+        # train) would then index past the tables, so the table sizes cover the largest id as well
+        self.num_users = max(len(self.user_items_dic), (max(self.user_items_dic) + 1) if self.user_items_dic else 0)
+        self.num_items = max(len(item_ids), (max(item_ids) + 1) if item_ids else 0)
         self._min_max = (min(self.user_items_dic) if self.user_items_dic else 0,
                          max(self.user_items_dic) if self.user_items_dic else 0,
                          min(item_ids) if item_ids else 0, max(item_ids) if item_ids else 0)

@@ -122,7 +122,10 @@ __global__ __launch_bounds__(64 * NW) void ccl_train_kernel(TrainArgs a)
     constexpr int R = 64 / LPR;            // rows fetched by one wave instruction
     constexpr int WCAP = NGW * R;          // negative slots held by one wave
     constexpr int NIDV = (WCAP + 63) / 64; // id registers per lane (lane k, register v: slot wave_base + v*64 + k)
-    constexpr int GPF = 4;                 // how many groups ahead the G rows may be fetched in the backward sweep
+    // how many groups ahead the G rows are fetched in the backward sweep: a short look-ahead keeps the read-modify-write
+    // window of a negative's G row small (fewer Hogwild collisions) where rows are small and hot; the multi-wave
+    // variants (large rows, large tables) fetch deep to cover HBM latency
+    constexpr int GPF = NW > 1 ? (NGW < 16 ? NGW : 16) : 4;
     const int lane = (int)(threadIdx.x & 63u);
     const int wave = NW == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t wave_base = (uint32_t)(wave * WCAP);
