@@ -29,6 +29,12 @@ class Config(C.Structure):
                 ("num_streams", C.c_uint32), ("update_mode", C.c_uint32)]
 
 
+class LightGCN(C.Structure):
+    _fields_ = [("num_lines", C.c_uint64), ("n_interactions", C.c_uint64), ("max_user_id", C.c_uint64),
+                ("max_item_id", C.c_uint64), ("clicks", C.POINTER(C.c_uint64)), ("line_user", C.POINTER(C.c_uint64)),
+                ("line_start", C.POINTER(C.c_uint64))]
+
+
 class DeviceView(C.Structure):
     _fields_ = [("user_w", C.c_void_p), ("item_w", C.c_void_p), ("user_g", C.c_void_p), ("item_g", C.c_void_p),
                 ("w0", C.c_void_p), ("clicks", C.c_void_p), ("data_rows", C.c_uint64), ("stream", C.c_void_p)]
@@ -63,6 +69,8 @@ SYMBOLS = {
     "heat_cf_zero_grad": (C.c_int, [C.c_void_p]),
     "heat_cf_kernel_time": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int]),
     "heat_cf_kernel_name": (C.c_char_p, [C.c_void_p]),
+    "heat_cf_parse_lightgcn": (C.c_int, [C.c_char_p, C.c_char, C.POINTER(LightGCN)]),
+    "heat_cf_free_lightgcn": (None, [C.POINTER(LightGCN)]),
 }
 
 _lib = None
@@ -119,6 +127,21 @@ def make_config(*, emb_dim, num_negs, num_users, num_items, train_size, neg_samp
 def _require(a, dtype, ndim, name):
     if not isinstance(a, np.ndarray) or a.dtype != dtype or a.ndim != ndim or not a.flags.c_contiguous:
         raise ValueError(f"{name} must be a C-contiguous {ndim}-D numpy array of {np.dtype(dtype).name}")
+
+
+def parse_lightgcn(path, separator=" "):
+    """(clicks [n,2] u64 in file order, line_user [lines] u64, line_start [lines+1] u64) of a LightGCN text file, parsed
+    natively (heat_cf_parse_lightgcn).  No GPU needed."""
+    g = LightGCN()
+    _check(load().heat_cf_parse_lightgcn(os.fsencode(path), separator.encode()[:1] or b" ", C.byref(g)))
+    try:
+        n, lines = int(g.n_interactions), int(g.num_lines)
+        clicks = np.ctypeslib.as_array(g.clicks, shape=(max(n, 1) * 2,))[:n * 2].reshape(n, 2).copy()
+        line_user = np.ctypeslib.as_array(g.line_user, shape=(max(lines, 1),))[:lines].copy()
+        line_start = np.ctypeslib.as_array(g.line_start, shape=(lines + 1,)).copy()
+    finally:
+        load().heat_cf_free_lightgcn(C.byref(g))
+    return clicks, line_user, line_start
 
 
 class Engine:

@@ -25,12 +25,12 @@ class ClickDataset(Dataset):
         self.max_his = config.max_his
         rnd = random.Random(seed)
         if user_items is None:
-            with open(file_path, mode='r') as in_file:
-                for line in in_file:
-                    splits = line.strip().split(separator)
-                    if not splits or splits[0] == '':
-                        continue
-                    self.user_items_dic[int(splits[0])] = [int(x) for x in splits[1:] if x != '']
+            # native one-pass parser (heat_cf_parse_lightgcn) instead of the reference's per-line Python loop
+            from heat_amd import abi
+            clicks, line_user, line_start = abi.parse_lightgcn(file_path, separator)
+            items_all = clicks[:, 1]
+            for k, u in enumerate(line_user.tolist()):
+                self.user_items_dic[u] = items_all[line_start[k]:line_start[k + 1]].tolist()   # a repeated user id: last line wins (datasets.py:56)
         else:
             self.user_items_dic = {int(u): [int(i) for i in items] for u, items in user_items.items()}
         # datasets.py:44-45: one history row per line, indexed by user id (sized by the largest id so that a file

@@ -200,10 +200,11 @@ __global__ __launch_bounds__(64 * NW) void ccl_train_kernel(TrainArgs a)
             const uint32_t user = (uint32_t)__builtin_amdgcn_readlane((int)pair.x, j);
             const uint32_t pos = (uint32_t)__builtin_amdgcn_readlane((int)pair.y, j);
             const uint64_t idx = base + (uint64_t)j;
-            if (NW > 1)
+            if (NW > 1 && a.exact_order)
             {
-                // B0: the previous interaction's row writes of EVERY wave are performed before any wave gathers again
-                // (within one wave program order already guarantees this; across waves nothing does)
+                // B0 (serial / parity mode only): the previous interaction's row writes of EVERY wave are performed before
+                // any wave gathers again (within one wave program order already guarantees this; across waves nothing
+                // does).  Hogwild runs skip it: the next gather overlaps the draining stores.
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
             }

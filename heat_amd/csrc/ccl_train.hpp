@@ -19,6 +19,7 @@ struct TrainArgs
     uint32_t     num_items, num_negs, emb_dim, row_bytes;
     uint32_t     item_bytes; // num_items * row_bytes (< 4 GiB: 32-bit buffer offsets)
     uint32_t     sampling_call;
+    uint32_t     exact_order; // serial/parity mode: order cross-wave row writes before the next gather
     uint32_t     tile_size;  // 0: uniform sampler; >0: random-tile sampler (used by the sampling() call only)
     uint32_t     refresh_interval;
     uint32_t     upd_bits;   // bit0 neg W atomic, bit1 neg G atomic, bit2 pos W atomic, bit3 pos G atomic

@@ -280,6 +280,7 @@ TrainArgs make_args(const heat_cf_engine* e, uint64_t begin, uint64_t end)
     a.row_bytes = (uint32_t)e->cfg.emb_dim * 4u;
     a.item_bytes = (uint32_t)(e->cfg.num_items * e->cfg.emb_dim * 4ull);
     a.sampling_call = (e->cfg.flags & HEAT_CF_FLAG_SAMPLING_CALL) ? 1u : 0u;
+    a.exact_order = (e->cfg.flags & HEAT_CF_FLAG_SERIAL) ? 1u : 0u;
     a.tile_size = e->cfg.neg_sampler == 1 ? (uint32_t)e->cfg.tile_size : 0u;
     a.refresh_interval = (uint32_t)std::max<uint64_t>(1, e->cfg.refresh_interval);
     a.upd_bits = (uint32_t)e->upd;
@@ -327,6 +328,9 @@ void destroy_impl(heat_cf_engine* e)
 } // namespace
 
 extern "C" {
+
+// used by ingest.cpp (host-only translation unit) to report errors through heat_cf_last_error()
+int heat_cf_set_error_(int code, const char* msg) { return fail(code, msg ? msg : ""); }
 
 int heat_cf_abi_version(void) { return HEAT_CF_ABI_VERSION; }
 

@@ -185,6 +185,23 @@ int      heat_cf_set_epoch(heat_cf_engine* e, uint64_t epoch);
 /* zero both persistent gradient tables (embeddings/embedding.cpp:41-45) */
 int      heat_cf_zero_grad(heat_cf_engine* e);
 
+/* LightGCN text ingest: parses "user item item ...\n" lines — the per-line Python loop of
+ * cf/datasets.py:31-79 — in one pass over the mmap'ed file.  Output (malloc'ed, release with heat_cf_free_lightgcn):
+ * clicks [n_interactions,2] u64 in FILE ORDER (datasets.py:74-78), line_user [num_lines] (user id of each line),
+ * line_start [num_lines+1] (first interaction of each line).  Host-only. */
+typedef struct heat_cf_lightgcn
+{
+    uint64_t  num_lines;
+    uint64_t  n_interactions;
+    uint64_t  max_user_id;
+    uint64_t  max_item_id;
+    uint64_t* clicks;
+    uint64_t* line_user;
+    uint64_t* line_start;
+} heat_cf_lightgcn;
+int  heat_cf_parse_lightgcn(const char* path, char separator, heat_cf_lightgcn* out);
+void heat_cf_free_lightgcn(heat_cf_lightgcn* g);
+
 /* Timing of the training kernel(s), measured with HIP events on the engine's stream:
  * accumulated kernel milliseconds and launch count since the last reset. */
 int heat_cf_kernel_time(heat_cf_engine* e, double* total_ms, uint64_t* launches, int reset);

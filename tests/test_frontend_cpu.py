@@ -177,3 +177,34 @@ def test_synthetic_graph_properties():
     tp, ep = g.train_indptr.astype(np.int64), g.test_indptr.astype(np.int64)
     for usr in range(0, 500, 37):
         assert not set(g.train_items[tp[usr]:tp[usr + 1]].tolist()) & set(g.test_items[ep[usr]:ep[usr + 1]].tolist())
+
+
+def test_native_lightgcn_ingest_matches_the_reference_loop(tmp_path):
+    """heat_cf_parse_lightgcn vs a restatement of the reference's per-line loop (cf/datasets.py:46-78): same pairs in
+    file order, empty users, trailing separators, CRLF; malformed input raises."""
+    from heat_amd import abi
+    rng = np.random.default_rng(0)
+    lines, want = [], []
+    for u in range(3000):
+        n = int(rng.integers(0, 40)) if u % 97 else 0          # some users without items
+        items = rng.integers(0, 50000, size=n).tolist()
+        tail = " " if u % 5 == 0 else ""
+        eol = "\r\n" if u % 7 == 0 else "\n"
+        lines.append(" ".join([str(u)] + [str(i) for i in items]) + tail + eol)
+        want.extend([u, i] for i in items)
+    path = tmp_path / "train.txt"
+    path.write_text("".join(lines))
+    clicks, line_user, line_start = abi.parse_lightgcn(str(path))
+    assert clicks.dtype == np.uint64 and clicks.tolist() == want
+    assert line_user.tolist() == list(range(3000)) and line_start[-1] == len(want)
+    assert line_start[97] == line_start[98]                    # user 97 has no items
+    empty = tmp_path / "empty.txt"
+    empty.write_text("")
+    c, lu, ls = abi.parse_lightgcn(str(empty))
+    assert c.shape == (0, 2) and lu.size == 0 and ls.tolist() == [0]
+    bad = tmp_path / "bad.txt"
+    bad.write_text("0 1 2\n1 x 3\n")
+    with pytest.raises(ValueError):
+        abi.parse_lightgcn(str(bad))
+    with pytest.raises(ValueError):
+        abi.parse_lightgcn(str(tmp_path / "missing.txt"))
