@@ -77,6 +77,10 @@ def main():
     if world > 1 or "RANK" in os.environ:
         dist.init_process_group("nccl", device_id=dev)
 
+    # one side stream carries everything: engine kernels, the torch element-wise ops of the item sync and (through
+    # torch.distributed's stream hand-off) the RCCL all-reduce are ordered with respect to each other
+    side = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(side)
     U, I, T, d, N = synthetic.SHAPES[args.shape]
     graph = None
     if args.shape == "synthetic_hbm":

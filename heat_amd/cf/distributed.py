@@ -52,7 +52,7 @@ class ItemSync:
             sync_interactions = streams * refresh_interval
         self.window = max(1, int(sync_interactions))   # clamped to the LARGEST shard inside train_one_epoch (same on every rank)
         self.ref = item_w.clone() if (mode == "sum" and world_size > 1) else None
-        self.force = False   # tests: run the collective even with one rank
+        self._n_max = None
         if mode not in ("sum", "mean"):
             raise ValueError("mode must be 'sum' or 'mean'")
 
@@ -77,13 +77,15 @@ class ItemSync:
         e = self.engine
         n = e.data_rows
         # every rank must run the same number of collectives: windows are counted on the largest shard
-        import torch
-        if self.world > 1:
-            t = torch.tensor([n], dtype=torch.int64, device=self.item_w.device)
-            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
-            n_max = int(t.item())
-        else:
-            n_max = n
+        if self._n_max is None:            # once: the shard sizes do not change between epochs
+            import torch
+            if self.world > 1:
+                t = torch.tensor([n], dtype=torch.int64, device=self.item_w.device)
+                self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+                self._n_max = int(t.item())
+            else:
+                self._n_max = n
+        n_max = self._n_max
         window = min(self.window, max(1, n_max))
         n_windows = max(1, -(-n_max // window))
         e.begin_epoch()

@@ -145,7 +145,7 @@ int common_init(heat_cf_engine* e, const heat_cf_config* cfg, uint64_t data_rows
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(HEAT_CF_EHIP, std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950 only");
     e->cu_count = (uint32_t)prop.multiProcessorCount;
-    if (stream)
+    if (stream || (cfg->flags & HEAT_CF_FLAG_NULL_STREAM))
     {
         e->stream = (hipStream_t)stream;
         e->own_stream = false;

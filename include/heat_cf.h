@@ -42,6 +42,8 @@ extern "C" {
 /* flags */
 #define HEAT_CF_FLAG_SERIAL        0x1u /* one wave walks all interactions in stored order (parity tests)      */
 #define HEAT_CF_FLAG_LAZY_SYNC     0x2u /* host mode: do not write weights back after every epoch              */
+#define HEAT_CF_FLAG_NULL_STREAM   0x8u /* device mode with stream == NULL: launch on the legacy default stream instead of
+                                           creating a private non-blocking one (callers whose other work is there)   */
 #define HEAT_CF_FLAG_SAMPLING_CALL 0x4u /* use sampler.sampling() (engine.cpp:333) instead of the live
                                            ignore_pos_sampling() (engine.cpp:332)                              */
 
