@@ -39,7 +39,8 @@ class ItemSync:
     """Drives `engine` (heat_amd.abi.Engine in device mode, or any object with begin_epoch / train_range / end_epoch /
     data_rows) through epochs cut into windows, all-reducing `item_w` (a torch tensor aliasing the engine's table)."""
 
-    def __init__(self, engine, item_w, world_size, refresh_interval=8192, sync_interactions=0, mode="sum", streams=0):
+    def __init__(self, engine, item_w, world_size, refresh_interval=8192, sync_interactions=0, mode="sum", streams=0,
+                 force_collective=False):
         import torch.distributed as dist
         self.dist = dist
         self.engine = engine
@@ -51,7 +52,8 @@ class ItemSync:
             streams = streams or getattr(engine, "num_streams", 0) or 3022
             sync_interactions = streams * refresh_interval
         self.window = max(1, int(sync_interactions))   # clamped to the LARGEST shard inside train_one_epoch (same on every rank)
-        self.ref = item_w.clone() if (mode == "sum" and world_size > 1) else None
+        self.force = bool(force_collective)     # run the collective path even with one rank (tests)
+        self.ref = item_w.clone() if (mode == "sum" and (world_size > 1 or self.force)) else None
         self._n_max = None
         if mode not in ("sum", "mean"):
             raise ValueError("mode must be 'sum' or 'mean'")
@@ -61,7 +63,7 @@ class ItemSync:
                 "window_interactions_per_gpu": min(self.window, self.engine.data_rows)}
 
     def sync(self):
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return
         if self.mode == "mean":
             self.dist.all_reduce(self.item_w, op=self.dist.ReduceOp.SUM)
