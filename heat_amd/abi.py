@@ -62,6 +62,7 @@ SYMBOLS = {
     "heat_cf_sync_from_host": (C.c_int, [C.c_void_p]),
     "heat_cf_synchronize": (C.c_int, [C.c_void_p]),
     "heat_cf_get_device_view": (C.c_int, [C.c_void_p, C.POINTER(DeviceView)]),
+    "heat_cf_copy_to_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
     "heat_cf_epoch": (C.c_uint64, [C.c_void_p]),
     "heat_cf_learning_rate": (C.c_float, [C.c_void_p]),
     "heat_cf_set_learning_rate": (C.c_int, [C.c_void_p, C.c_float]),
@@ -80,6 +81,14 @@ def load():
     """dlopen lib/libheat_cf.so and type every entry point.  Raises if the HIP library is missing."""
     global _lib
     if _lib is None:
+        # One HIP runtime per process: torch ships its own libamdhip64.so.7 and libheat_cf.so depends on the same SONAME, so
+        # whichever is loaded first serves both.  Loading torch's first keeps torch usable next to the engine (device
+        # tensors, streams, torch.distributed/RCCL); the other order leaves torch without visible GPUs.
+        try:
+            import torch  # noqa: F401
+            torch.cuda.is_available()
+        except ImportError:
+            pass
         if not os.path.exists(LIB_PATH):
             raise ImportError(f"{LIB_PATH} is missing: build it with `python -m heat_amd.build` "
                               "(hipcc --offload-arch=gfx950); heat_amd has no CPU fallback")
@@ -238,6 +247,12 @@ class Engine:
 
     def zero_grad(self):
         _check(load().heat_cf_zero_grad(self._h))
+
+    def read_device(self, ptr, shape, dtype=np.float32):
+        """Host copy of a device buffer (e.g. device_view().item_g)."""
+        out = np.empty(shape, dtype=dtype)
+        _check(load().heat_cf_copy_to_host(self._h, C.c_void_p(ptr), _ptr(out), out.nbytes))
+        return out
 
     def device_view(self):
         v = DeviceView()

@@ -771,6 +771,15 @@ int heat_cf_get_device_view(heat_cf_engine* e, heat_cf_device_view* view)
     return HEAT_CF_OK;
 }
 
+int heat_cf_copy_to_host(heat_cf_engine* e, const void* device_ptr, void* host_ptr, uint64_t bytes)
+{
+    if (!e || !device_ptr || !host_ptr) return fail(HEAT_CF_EINVAL, "engine / pointer is NULL");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipMemcpyAsync(host_ptr, device_ptr, (size_t)bytes, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return HEAT_CF_OK;
+}
+
 uint64_t heat_cf_epoch(const heat_cf_engine* e) { return e ? e->epoch : 0; }
 float    heat_cf_learning_rate(const heat_cf_engine* e) { return e ? e->lr : 0.f; }
 

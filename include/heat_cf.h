@@ -178,6 +178,8 @@ int heat_cf_sync_from_host(heat_cf_engine* e);
 int heat_cf_synchronize(heat_cf_engine* e);
 
 int heat_cf_get_device_view(heat_cf_engine* e, heat_cf_device_view* view);
+/* copies `bytes` from device memory (e.g. a table of the device view) to HOST memory on the engine's stream and waits */
+int heat_cf_copy_to_host(heat_cf_engine* e, const void* device_ptr, void* host_ptr, uint64_t bytes);
 
 /* scalar state */
 uint64_t heat_cf_epoch(const heat_cf_engine* e);
