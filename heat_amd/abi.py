@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libheat_cf.so")
+LIB_PATH = os.environ.get("HEAT_CF_LIB") or os.path.join(HERE, "lib", "libheat_cf.so")   # HEAT_CF_LIB: development builds
 
 OK, EINVAL, EHIP, ENOMEM, EUNSUP = 0, -1, -2, -3, -4
 FLAG_SERIAL, FLAG_LAZY_SYNC, FLAG_SAMPLING_CALL, FLAG_NULL_STREAM = 0x1, 0x2, 0x4, 0x8

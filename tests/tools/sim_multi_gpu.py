@@ -8,7 +8,7 @@ import types
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from heat_amd.cf import metrics, synthetic
 from heat_amd.cf.distributed import shard_clicks
 from oracle import cf_oracle as orc
