@@ -402,3 +402,46 @@ def test_device_mode_engine_with_item_sync_on_a_side_stream():
         np.testing.assert_allclose(u1, u0, rtol=0, atol=2e-5)
     finally:
         dist.destroy_process_group()
+
+
+def test_edge_shapes_empty_single_tiny():
+    """Edge cases the domain has: an empty interaction list, a single interaction, one negative, emb_dim = 4, more
+    negatives than items (duplicates guaranteed), a ragged tail (n % 64 != 0), users without interactions."""
+    # empty
+    uw, iw = synthetic.init_embeddings(3, 5, 64)
+    u0 = uw.copy()
+    eng = abi.Engine(np.zeros((0, 2), dtype=np.uint64), uw, iw, num_negs=4)
+    assert eng.train_one_epoch() == 0.0 and eng.epoch == 1 and np.array_equal(uw, u0)
+    eng.close()
+    # single interaction, one negative, emb_dim 4, vs the oracle
+    for d, N, I in [(4, 1, 6), (64, 16, 3), (8, 5, 2)]:
+        rng = np.random.default_rng(d)
+        uw = (rng.standard_normal((2, d)) * 0.1).astype(np.float32)
+        iw = (rng.standard_normal((I, d)) * 0.1).astype(np.float32)
+        uo, io = uw.copy(), iw.copy()
+        clicks = np.array([[1, 0]], dtype=np.uint64)
+        negs = rng.integers(0, I, size=(1, N)).astype(np.uint64)
+        eng = abi.Engine(clicks, uw, iw, num_negs=N, flags=abi.FLAG_SERIAL)
+        lg = eng.train_range(0, 1, negs)
+        eng.sync_to_host(); eng.close()
+        lo = orc.Engine(clicks, uo, io, num_negs=N).train_range(0, 1, negs)
+        assert abs(lg - lo) <= 1e-5 * max(1.0, abs(lo))
+        np.testing.assert_allclose(uw, uo, rtol=0, atol=2e-7)
+        np.testing.assert_allclose(iw, io, rtol=0, atol=2e-7)
+        assert np.array_equal(uw[0], uo[0])                      # user 0 has no interactions: untouched
+
+
+def test_windows_compose_to_the_whole_range():
+    """train_range(0,a) + train_range(a,n) == train_range(0,n) in serial mode (multi-GPU windows cut epochs this way);
+    sampling() call so that the negatives do not depend on where a window starts."""
+    d, N, U, I, T = 64, 16, 30, 500, 1000
+    clicks, uw, iw = small_problem(U, I, T, d, seed=12)
+    outs = []
+    for cuts in ([0, T], [0, 1, 65, 300, 777, T]):
+        a, b = uw.copy(), iw.copy()
+        eng = abi.Engine(clicks, a, b, num_negs=N, seed=9, flags=abi.FLAG_SERIAL | abi.FLAG_SAMPLING_CALL)
+        loss = sum(eng.train_range(lo, hi) for lo, hi in zip(cuts[:-1], cuts[1:]))
+        eng.sync_to_host(); eng.close()
+        outs.append((a, b, loss))
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    assert abs(outs[0][2] - outs[1][2]) < 1e-9 * abs(outs[0][2])
