@@ -24,6 +24,9 @@
 #include "ccl_device.hpp"
 #include "ccl_train.hpp"
 
+#include <cstdio>
+#include <cstdlib>
+
 namespace heatcf
 {
 
@@ -679,20 +682,43 @@ static hipError_t launch_variant(const TrainArgs& a, uint32_t grid, int aux, hip
 #define HEATCF_VARIANTS(X) \
     X(8, 1, 1) X(8, 2, 1) X(8, 4, 1) X(8, 8, 1) X(8, 16, 1) \
     X(16, 2, 1) X(16, 4, 1) X(16, 8, 1) X(16, 16, 1) X(16, 16, 2) \
-    X(32, 4, 1) X(32, 8, 1) X(32, 16, 1) X(32, 16, 2) X(32, 16, 4) \
-    X(64, 8, 1) X(64, 16, 1) X(64, 16, 2) X(64, 16, 4) X(64, 25, 4) X(64, 16, 8)
+    X(32, 4, 1) X(32, 8, 1) X(32, 16, 1) X(32, 32, 1) X(32, 16, 2) X(32, 8, 4) X(32, 16, 4) \
+    X(64, 8, 1) X(64, 16, 1) X(64, 16, 2) X(64, 16, 4) X(64, 25, 4) X(64, 13, 8) X(64, 16, 8)
 #endif
 
-bool pick_variant(uint32_t emb_dim, uint32_t num_negs, int* lpr_out, int* ng_out, int* nw_out)
+bool pick_variant(uint32_t emb_dim, uint32_t num_negs, bool single_wave, int* lpr_out, int* ng_out, int* nw_out)
 {
     if (emb_dim == 0 || emb_dim % 4 != 0 || emb_dim > 256 || num_negs == 0) return false;
     const uint32_t need = emb_dim / 4;
     int lpr = 8;
     while ((uint32_t)lpr < need) lpr <<= 1;
     const int R = 64 / lpr;
+    // sizing sweeps (BASELINE.json configs[2]): HEAT_CF_VARIANT="groups,waves" forces a compiled variant with enough capacity
+    if (const char* ov = std::getenv("HEAT_CF_VARIANT"))
+    {
+        int g = 0, w = 0;
+        if (std::sscanf(ov, "%d,%d", &g, &w) == 2)
+        {
+            bool ok = false;
+#define X(L, G, W) if (L == lpr && G == g && W == w && (uint32_t)(G * R * W) >= num_negs && (!single_wave || W == 1)) ok = true;
+            HEATCF_VARIANTS(X)
+#undef X
+            if (ok)
+            {
+                *lpr_out = lpr;
+                *ng_out = g;
+                *nw_out = w;
+                return true;
+            }
+            return false;
+        }
+    }
     int best_cap = 0, best_g = 0, best_w = 0;
+    // smallest capacity that fits; among equals the fewest register groups per wave (= most waves per workgroup):
+    // measured at Yelp18 shape <32,8,4> 0.81 > <32,16,2> 0.78 > <32,32,1> 0.74 of HBM peak (profiles/r01_variant_sweep.txt)
 #define X(L, G, W)                                                                                   \
-    if (L == lpr && (uint32_t)(G * R * W) >= num_negs && (best_cap == 0 || G * R * W < best_cap))      \
+    if (L == lpr && (uint32_t)(G * R * W) >= num_negs && (!single_wave || W == 1) &&                   \
+        (best_cap == 0 || G * R * W < best_cap || (G * R * W == best_cap && G < best_g)))              \
     {                                                                                                  \
         best_cap = G * R * W;                                                                          \
         best_g = G;                                                                                    \

@@ -44,7 +44,7 @@ struct TrainArgs
 // per-epoch sampler key: (seed, epoch) -> 64-bit Philox key (= the `seed` argument of hiprand_init)
 inline uint64_t epoch_key(uint64_t seed, uint64_t epoch) { return seed + 0x9E3779B97F4A7C15ull * (epoch + 1ull); }
 
-bool       pick_variant(uint32_t emb_dim, uint32_t num_negs, int* lpr, int* ng, int* nw);
+bool       pick_variant(uint32_t emb_dim, uint32_t num_negs, bool single_wave, int* lpr, int* ng, int* nw);
 hipError_t launch_train(const TrainArgs& a, int lpr, int ng, int nw, uint32_t grid, int aux, hipStream_t s);
 hipError_t launch_loss_reduce(const double* part, uint32_t n, double* out, hipStream_t s);
 hipError_t launch_pack_clicks(const uint64_t* in, uint2* out, uint64_t n, uint32_t* stats, hipStream_t s);

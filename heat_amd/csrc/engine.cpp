@@ -112,7 +112,7 @@ int validate_cfg(const heat_cf_config* cfg, uint64_t data_rows, int* lpr, int* n
     if (cfg->neg_sampler != 0 && cfg->neg_sampler != 1) return fail(HEAT_CF_EINVAL, "neg_sampler must be 0 or 1");
     if (cfg->neg_sampler == 1 && (cfg->tile_size == 0 || cfg->tile_size > 0xFFFFFFFFull || cfg->refresh_interval == 0))
         return fail(HEAT_CF_EINVAL, "random-tile sampler needs tile_size > 0 and refresh_interval > 0");
-    if (!pick_variant((uint32_t)cfg->emb_dim, (uint32_t)cfg->num_negs, lpr, ng, nw))
+    if (!pick_variant((uint32_t)cfg->emb_dim, (uint32_t)cfg->num_negs, cfg->use_aggregator != 0, lpr, ng, nw))
         return fail(HEAT_CF_EUNSUP, "no compiled kernel variant for this (emb_dim, num_negs)");
     if (data_rows >= (1ull << 40)) return fail(HEAT_CF_EINVAL, "data_rows too large");
     return HEAT_CF_OK;
