@@ -159,10 +159,10 @@ int common_init(heat_cf_engine* e, const heat_cf_config* cfg, uint64_t data_rows
     if (coh != HEAT_CF_COHERENCE_PLAIN && coh != HEAT_CF_COHERENCE_DEVICE) return fail(HEAT_CF_EINVAL, "bad coherence");
     e->aux = coh == HEAT_CF_COHERENCE_DEVICE ? 16 : 0;
     // streams: enough sequential walkers to fill the chip, but never more asynchrony than was validated against the
-    // oracle at AmazonBooks shape (3072 streams over 91 599 items / 52 643 users)
+    // oracle at AmazonBooks shape: 3072 streams x 17 item rows in flight over 91 599 item rows = 0.56 in-flight touches
+    // per item row (and 5.8 % of the users in flight)
     {
         const int lpr = e->lpr, ng = e->ng;
-        // measured register footprints: <=4 register groups fit 3 waves/SIMD, <=8 fit 2, the rest 1
         // register footprint ~ 8 VGPRs per group + ~60: waves per SIMD the kernel can hold
         const uint32_t vg = 60u + 8u * (uint32_t)ng;
         const uint32_t waves_per_simd = vg <= 64 ? 8u : (vg <= 96 ? 5u : (vg <= 128 ? 4u : (vg <= 168 ? 3u : (vg <= 256 ? 2u : 1u))));
@@ -175,7 +175,7 @@ int common_init(heat_cf_engine* e, const heat_cf_config* cfg, uint64_t data_rows
             const uint64_t per_cu = std::max<uint64_t>(1, (160 * 1024) / lds);
             fill = std::min<uint64_t>(fill, (uint64_t)e->cu_count * per_cu);
         }
-        const uint64_t cap_items = (uint64_t)(0.033 * (double)cfg->num_items);
+        const uint64_t cap_items = (uint64_t)(0.56 * (double)cfg->num_items / (double)(cfg->num_negs + 1));
         const uint64_t cap_users = (uint64_t)(0.058 * (double)cfg->num_users);
         uint64_t streams = std::min(fill, std::min(cap_items, cap_users));
         if (streams < 1) streams = 1;
