@@ -188,7 +188,7 @@ int common_init(heat_cf_engine* e, const heat_cf_config* cfg, uint64_t data_rows
     {
         const double streams = (double)(cfg->num_streams ? cfg->num_streams : e->auto_streams);
         const double touches = streams * (double)cfg->num_negs / (double)cfg->num_items;
-        um = touches <= 0.55 ? HEAT_CF_UPDATE_ATOMIC_POS : HEAT_CF_UPDATE_ATOMIC_WG;
+        um = touches <= 0.56 ? HEAT_CF_UPDATE_ATOMIC_POS : HEAT_CF_UPDATE_ATOMIC_WG;
     }
     uint32_t bits;
     if (um == HEAT_CF_UPDATE_OVERWRITE) bits = 0u;

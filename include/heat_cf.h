@@ -63,7 +63,7 @@ extern "C" {
 #define HEAT_CF_UPDATE_ATOMIC_WG  3 /* W and G by atomic add for every item row: no update is ever lost              */
 #define HEAT_CF_UPDATE_ATOMIC_POS 4 /* positive item row: W and G by atomic add; negative rows: overwrite            */
 #define HEAT_CF_UPDATE_AUTO       5 /* ATOMIC_POS while the expected number of concurrent touches of a negative row,
-                                       streams * num_negs / num_items, is <= 0.55 (the regime validated against the
+                                       streams * num_negs / num_items, is <= 0.56 (the regime validated against the
                                        oracle), ATOMIC_WG otherwise                                                   */
 /* values 16..31: raw policy bits (16 + bit0 neg W atomic + bit1 neg G atomic + bit2 pos W atomic + bit3 pos G atomic) */
 

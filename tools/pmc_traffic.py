@@ -23,7 +23,7 @@ if __name__ == "__main__":
     fetch_kib, n1 = mean_counter(fetch_csv, "FETCH_SIZE", "ccl_train_kernel")
     write_kib, n2 = mean_counter(write_csv, "WRITE_SIZE", "ccl_train_kernel")
     res = {
-        "kernel": "ccl_train_kernel<16,4,16>", "workload": "bench.py default (AmazonBooks shape, 2380730 interactions per launch)",
+        "kernel": "ccl_train_kernel<16,4,16,1>", "workload": "bench.py default (AmazonBooks shape, 2380730 interactions per launch)",
         "launches_averaged": [n1, n2],
         "FETCH_SIZE_KiB_raw": fetch_kib, "WRITE_SIZE_KiB_raw": write_kib,
         "fetch_bytes_per_launch": fetch_kib * 1024 * 2,     # gfx950: x2 for 16 B/lane reads
