@@ -406,7 +406,6 @@ __global__ __launch_bounds__(64 * NW) HEATCF_OCC void ccl_train_kernel(TrainArgs
                 mx = fmaxf(mx, es[g]);
             }
             mx = cross_max<LPR>(mx);
-            float wmx = mx;                                             // this wave's maximum
             if (NW > 1)
             {
                 if (lane == 0) sh_stat[wave * 2] = mx;
@@ -414,7 +413,6 @@ __global__ __launch_bounds__(64 * NW) HEATCF_OCC void ccl_train_kernel(TrainArgs
 #pragma unroll
                 for (int w = 0; w < NW; ++w) mx = fmaxf(mx, sh_stat[w * 2]);
             }
-            (void)wmx;
             float ssum = 0.0f;
 #pragma unroll
             for (int g = 0; g < NGW; ++g)
@@ -739,6 +737,37 @@ hipError_t launch_train(const TrainArgs& a, int lpr, int ng, int nw, uint32_t gr
     HEATCF_VARIANTS(X)
 #undef X
     return hipErrorInvalidValue;
+}
+
+// resident workgroups per CU of the variant the engine will launch (register / LDS limited), from the runtime
+template <int LPR, int NGW, int NW>
+static int occupancy_variant(int aux, bool agg, uint32_t emb_dim)
+{
+    int blocks = 0;
+    hipError_t e = hipErrorInvalidValue;
+    if (agg)
+    {
+        if constexpr (NW == 1)
+        {
+            const size_t lds = ((size_t)emb_dim * emb_dim + 32 * 2 * 4 * LPR + 4 * LPR) * sizeof(float);
+            auto kern = ccl_train_kernel<LPR, NGW, AUX_SC1, 1, true>;
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, kern, 64, lds);
+        }
+    }
+    else if (aux == AUX_PLAIN)
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, ccl_train_kernel<LPR, NGW, AUX_PLAIN, NW, false>, 64 * NW, 0);
+    else
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, ccl_train_kernel<LPR, NGW, AUX_SC1, NW, false>, 64 * NW, 0);
+    return e == hipSuccess ? blocks : 0;
+}
+
+int query_blocks_per_cu(int lpr, int ng, int nw, int aux, bool agg, uint32_t emb_dim)
+{
+#define X(L, G, W) if (lpr == L && ng == G && nw == W) return occupancy_variant<L, G, W>(aux, agg, emb_dim);
+    HEATCF_VARIANTS(X)
+#undef X
+    return 0;
 }
 
 hipError_t launch_loss_reduce(const double* part, uint32_t n, double* out, hipStream_t s)

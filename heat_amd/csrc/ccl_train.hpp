@@ -46,6 +46,7 @@ inline uint64_t epoch_key(uint64_t seed, uint64_t epoch) { return seed + 0x9E377
 
 bool       pick_variant(uint32_t emb_dim, uint32_t num_negs, bool single_wave, int* lpr, int* ng, int* nw);
 hipError_t launch_train(const TrainArgs& a, int lpr, int ng, int nw, uint32_t grid, int aux, hipStream_t s);
+int        query_blocks_per_cu(int lpr, int ng, int nw, int aux, bool agg, uint32_t emb_dim);
 hipError_t launch_loss_reduce(const double* part, uint32_t n, double* out, hipStream_t s);
 hipError_t launch_pack_clicks(const uint64_t* in, uint2* out, uint64_t n, uint32_t* stats, hipStream_t s);
 hipError_t launch_sample_negs(const TrainArgs& a, uint32_t grid, uint64_t out_base, uint64_t* out, hipStream_t s);

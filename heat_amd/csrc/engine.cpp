@@ -162,19 +162,10 @@ int common_init(heat_cf_engine* e, const heat_cf_config* cfg, uint64_t data_rows
     // oracle at AmazonBooks shape: 3072 streams x 17 item rows in flight over 91 599 item rows = 0.56 in-flight touches
     // per item row (and 5.8 % of the users in flight)
     {
-        const int lpr = e->lpr, ng = e->ng;
-        // register footprint ~ 8 VGPRs per group + ~60: waves per SIMD the kernel can hold
-        const uint32_t vg = 60u + 8u * (uint32_t)ng;
-        const uint32_t waves_per_simd = vg <= 64 ? 8u : (vg <= 96 ? 5u : (vg <= 128 ? 4u : (vg <= 168 ? 3u : (vg <= 256 ? 2u : 1u))));
-        (void)lpr;
-        uint64_t fill = (uint64_t)e->cu_count * 4ull * waves_per_simd / (uint64_t)e->nw;   // workgroups (= streams)
-        if (fill < e->cu_count) fill = e->cu_count;
-        if (cfg->use_aggregator)
-        {
-            const uint64_t lds = (cfg->emb_dim * cfg->emb_dim + 32 * 2 * 4 * (uint64_t)lpr + 4 * (uint64_t)lpr) * 4 + 1024;
-            const uint64_t per_cu = std::max<uint64_t>(1, (160 * 1024) / lds);
-            fill = std::min<uint64_t>(fill, (uint64_t)e->cu_count * per_cu);
-        }
+        // resident workgroups per CU as the runtime reports them for this variant (register / LDS limited)
+        int per_cu = query_blocks_per_cu(e->lpr, e->ng, e->nw, e->aux, cfg->use_aggregator != 0, (uint32_t)cfg->emb_dim);
+        if (per_cu < 1) per_cu = 1;
+        const uint64_t fill = (uint64_t)e->cu_count * (uint64_t)per_cu;   // workgroups (= streams) that run concurrently
         const uint64_t cap_items = (uint64_t)(0.56 * (double)cfg->num_items / (double)(cfg->num_negs + 1));
         const uint64_t cap_users = (uint64_t)(0.058 * (double)cfg->num_users);
         uint64_t streams = std::min(fill, std::min(cap_items, cap_users));
