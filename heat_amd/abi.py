@@ -45,6 +45,7 @@ SYMBOLS = {
     "heat_cf_abi_version": (C.c_int, []),
     "heat_cf_last_error": (C.c_char_p, []),
     "heat_cf_device_count": (C.c_int, []),
+    "heat_cf_plan": (C.c_int, [C.POINTER(Config), C.c_uint64, C.c_uint64, C.c_char_p, C.c_uint64]),
     "heat_cf_engine_create": (C.c_int, [C.POINTER(Config), C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
     "heat_cf_engine_create_device": (C.c_int, [C.POINTER(Config), C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
@@ -136,6 +137,15 @@ def make_config(*, emb_dim, num_negs, num_users, num_items, train_size, neg_samp
 def _require(a, dtype, ndim, name):
     if not isinstance(a, np.ndarray) or a.dtype != dtype or a.ndim != ndim or not a.flags.c_contiguous:
         raise ValueError(f"{name} must be a C-contiguous {ndim}-D numpy array of {np.dtype(dtype).name}")
+
+
+def plan(resident_workgroups=0, data_rows=None, **cfg_kwargs):
+    """The launch plan (kernel variant, streams, update policy) for a configuration, as a dict.  No GPU needed."""
+    import json
+    cfg = make_config(**cfg_kwargs)
+    buf = C.create_string_buffer(512)
+    _check(load().heat_cf_plan(C.byref(cfg), cfg.train_size if data_rows is None else data_rows, resident_workgroups, buf, 512))
+    return json.loads(buf.value.decode())
 
 
 def parse_lightgcn(path, separator=" "):

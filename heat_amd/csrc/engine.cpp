@@ -119,6 +119,58 @@ int validate_cfg(const heat_cf_config* cfg, uint64_t data_rows, int* lpr, int* n
     return HEAT_CF_OK;
 }
 
+// ---- launch plan: pure host logic (no HIP calls), shared by engine creation and heat_cf_plan() ----------------------
+struct Plan
+{
+    int      lpr = 0, ng = 0, nw = 1;
+    uint32_t coherence = 0;   // resolved HEAT_CF_COHERENCE_*
+    uint32_t streams = 1;     // workgroups walking the list concurrently
+    uint32_t cap_items = 0, cap_users = 0;
+    uint32_t update_mode = 0; // resolved HEAT_CF_UPDATE_* (or the raw 16.. form)
+    uint32_t upd_bits = 0;
+};
+
+// fill = workgroups the chip can keep resident for the chosen variant (from the occupancy query; 0 = unknown: caps only)
+int make_plan(const heat_cf_config* cfg, uint64_t data_rows, uint64_t fill, Plan* p)
+{
+    int rc = validate_cfg(cfg, data_rows, &p->lpr, &p->ng, &p->nw);
+    if (rc) return rc;
+    const uint32_t coh = cfg->coherence == HEAT_CF_COHERENCE_DEFAULT ? HEAT_CF_COHERENCE_DEVICE : cfg->coherence;
+    if (coh != HEAT_CF_COHERENCE_PLAIN && coh != HEAT_CF_COHERENCE_DEVICE) return fail(HEAT_CF_EINVAL, "bad coherence");
+    p->coherence = coh;
+    // streams: enough sequential walkers to fill the chip, but never more asynchrony than was validated against the
+    // oracle at AmazonBooks shape: 3072 streams x 17 item rows in flight over 91 599 item rows = 0.56 in-flight touches
+    // per item row (and 5.8 % of the users in flight)
+    p->cap_items = (uint32_t)std::min<uint64_t>(0xFFFFFFFFull, (uint64_t)(0.56 * (double)cfg->num_items / (double)(cfg->num_negs + 1)));
+    p->cap_users = (uint32_t)std::min<uint64_t>(0xFFFFFFFFull, (uint64_t)(0.058 * (double)cfg->num_users));
+    uint64_t streams = std::min<uint64_t>(p->cap_items, p->cap_users);
+    if (fill) streams = std::min(streams, fill);
+    if (streams < 1) streams = 1;
+    if (cfg->num_streams) streams = cfg->num_streams;
+    if (cfg->flags & HEAT_CF_FLAG_SERIAL) streams = 1;
+    p->streams = (uint32_t)streams;
+    uint32_t um = cfg->update_mode;
+    if (um == HEAT_CF_UPDATE_DEFAULT) um = HEAT_CF_UPDATE_AUTO;
+    if (coh != HEAT_CF_COHERENCE_DEVICE && um == HEAT_CF_UPDATE_AUTO) um = HEAT_CF_UPDATE_OVERWRITE;
+    if (um == HEAT_CF_UPDATE_AUTO)
+    {
+        const double touches = (double)streams * (double)cfg->num_negs / (double)cfg->num_items;
+        um = touches <= 0.56 ? HEAT_CF_UPDATE_ATOMIC_POS : HEAT_CF_UPDATE_ATOMIC_WG;
+    }
+    uint32_t bits;
+    if (um == HEAT_CF_UPDATE_OVERWRITE) bits = 0u;
+    else if (um == HEAT_CF_UPDATE_ATOMIC_W) bits = 0x5u;
+    else if (um == HEAT_CF_UPDATE_ATOMIC_WG) bits = 0xFu;
+    else if (um == HEAT_CF_UPDATE_ATOMIC_POS) bits = 0xCu;
+    else if (um >= 16u && um < 32u) bits = um - 16u;
+    else return fail(HEAT_CF_EINVAL, "bad update_mode");
+    if (bits != 0u && coh != HEAT_CF_COHERENCE_DEVICE)
+        return fail(HEAT_CF_EINVAL, "atomic update modes need HEAT_CF_COHERENCE_DEVICE");
+    p->update_mode = um;
+    p->upd_bits = bits;
+    return HEAT_CF_OK;
+}
+
 int common_init(heat_cf_engine* e, const heat_cf_config* cfg, uint64_t data_rows, void* stream)
 {
     e->cfg = *cfg;
@@ -156,42 +208,17 @@ int common_init(heat_cf_engine* e, const heat_cf_config* cfg, uint64_t data_rows
         HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
         e->own_stream = true;
     }
-    const uint32_t coh = cfg->coherence == HEAT_CF_COHERENCE_DEFAULT ? HEAT_CF_COHERENCE_DEVICE : cfg->coherence;
-    if (coh != HEAT_CF_COHERENCE_PLAIN && coh != HEAT_CF_COHERENCE_DEVICE) return fail(HEAT_CF_EINVAL, "bad coherence");
-    e->aux = coh == HEAT_CF_COHERENCE_DEVICE ? 16 : 0;
-    // streams: enough sequential walkers to fill the chip, but never more asynchrony than was validated against the
-    // oracle at AmazonBooks shape: 3072 streams x 17 item rows in flight over 91 599 item rows = 0.56 in-flight touches
-    // per item row (and 5.8 % of the users in flight)
-    {
-        // resident workgroups per CU as the runtime reports them for this variant (register / LDS limited)
-        int per_cu = query_blocks_per_cu(e->lpr, e->ng, e->nw, e->aux, cfg->use_aggregator != 0, (uint32_t)cfg->emb_dim);
-        if (per_cu < 1) per_cu = 1;
-        const uint64_t fill = (uint64_t)e->cu_count * (uint64_t)per_cu;   // workgroups (= streams) that run concurrently
-        const uint64_t cap_items = (uint64_t)(0.56 * (double)cfg->num_items / (double)(cfg->num_negs + 1));
-        const uint64_t cap_users = (uint64_t)(0.058 * (double)cfg->num_users);
-        uint64_t streams = std::min(fill, std::min(cap_items, cap_users));
-        if (streams < 1) streams = 1;
-        e->auto_streams = (uint32_t)streams;
-    }
-    uint32_t um = cfg->update_mode;
-    if (um == HEAT_CF_UPDATE_DEFAULT) um = HEAT_CF_UPDATE_AUTO;
-    if (coh != HEAT_CF_COHERENCE_DEVICE && um == HEAT_CF_UPDATE_AUTO) um = HEAT_CF_UPDATE_OVERWRITE;
-    if (um == HEAT_CF_UPDATE_AUTO)
-    {
-        const double streams = (double)(cfg->num_streams ? cfg->num_streams : e->auto_streams);
-        const double touches = streams * (double)cfg->num_negs / (double)cfg->num_items;
-        um = touches <= 0.56 ? HEAT_CF_UPDATE_ATOMIC_POS : HEAT_CF_UPDATE_ATOMIC_WG;
-    }
-    uint32_t bits;
-    if (um == HEAT_CF_UPDATE_OVERWRITE) bits = 0u;
-    else if (um == HEAT_CF_UPDATE_ATOMIC_W) bits = 0x5u;
-    else if (um == HEAT_CF_UPDATE_ATOMIC_WG) bits = 0xFu;
-    else if (um == HEAT_CF_UPDATE_ATOMIC_POS) bits = 0xCu;
-    else if (um >= 16u && um < 32u) bits = um - 16u;
-    else return fail(HEAT_CF_EINVAL, "bad update_mode");
-    if (bits != 0u && coh != HEAT_CF_COHERENCE_DEVICE)
-        return fail(HEAT_CF_EINVAL, "atomic update modes need HEAT_CF_COHERENCE_DEVICE");
-    e->upd = (int)bits;
+    Plan plan;
+    int prc = make_plan(cfg, data_rows, 0, &plan);       // variant + coherence first: the occupancy query needs them
+    if (prc) return prc;
+    e->aux = plan.coherence == HEAT_CF_COHERENCE_DEVICE ? 16 : 0;
+    // resident workgroups per CU as the runtime reports them for this variant (register / LDS limited)
+    int per_cu = query_blocks_per_cu(e->lpr, e->ng, e->nw, e->aux, cfg->use_aggregator != 0, (uint32_t)cfg->emb_dim);
+    if (per_cu < 1) per_cu = 1;
+    prc = make_plan(cfg, data_rows, (uint64_t)e->cu_count * (uint64_t)per_cu, &plan);
+    if (prc) return prc;
+    e->auto_streams = plan.streams;
+    e->upd = (int)plan.upd_bits;
     std::snprintf(e->kname, sizeof(e->kname), "ccl_train_kernel<%d,%d,%d,%d>/upd=0x%x", e->lpr, e->ng, e->aux, e->nw, (unsigned)e->upd);
     HIP_TRY(hipMalloc(&e->d_sums, 2 * sizeof(double)));
     HIP_TRY(hipMemsetAsync(e->d_sums, 0, 2 * sizeof(double), e->stream));
@@ -248,7 +275,7 @@ void geometry(const heat_cf_engine* e, uint64_t n, uint64_t* per_block, uint32_t
         *grid = 1;
         return;
     }
-    uint64_t streams = e->cfg.num_streams ? e->cfg.num_streams : (uint64_t)e->auto_streams;
+    uint64_t streams = (uint64_t)e->auto_streams;
     uint64_t pb = (n + streams - 1) / streams;
     pb = ((pb + 63) / 64) * 64;
     if (pb == 0) pb = 64;
@@ -329,6 +356,27 @@ int heat_cf_set_error_(int code, const char* msg) { return fail(code, msg ? msg 
 int heat_cf_abi_version(void) { return HEAT_CF_ABI_VERSION; }
 
 const char* heat_cf_last_error(void) { return g_last_error.c_str(); }
+
+int heat_cf_plan(const heat_cf_config* cfg, uint64_t data_rows, uint64_t resident_workgroups, char* out, uint64_t out_bytes)
+{
+    if (!cfg || !out || out_bytes == 0) return fail(HEAT_CF_EINVAL, "cfg / out is NULL");
+    Plan p;
+    int rc = make_plan(cfg, data_rows, resident_workgroups, &p);
+    if (rc) return rc;
+    const char* um = p.update_mode == HEAT_CF_UPDATE_OVERWRITE ? "OVERWRITE"
+                   : p.update_mode == HEAT_CF_UPDATE_ATOMIC_W ? "ATOMIC_W"
+                   : p.update_mode == HEAT_CF_UPDATE_ATOMIC_WG ? "ATOMIC_WG"
+                   : p.update_mode == HEAT_CF_UPDATE_ATOMIC_POS ? "ATOMIC_POS" : "RAW";
+    const int n = std::snprintf(out, (size_t)out_bytes,
+                                "{\"lanes_per_row\": %d, \"groups_per_wave\": %d, \"waves_per_workgroup\": %d, "
+                                "\"negative_capacity\": %d, \"coherence\": \"%s\", \"streams\": %u, \"cap_items\": %u, "
+                                "\"cap_users\": %u, \"update_mode\": \"%s\", \"update_bits\": %u}",
+                                p.lpr, p.ng, p.nw, p.ng * (64 / p.lpr) * p.nw,
+                                p.coherence == HEAT_CF_COHERENCE_DEVICE ? "device" : "plain", p.streams, p.cap_items,
+                                p.cap_users, um, p.upd_bits);
+    if (n < 0 || (uint64_t)n >= out_bytes) return fail(HEAT_CF_EINVAL, "out buffer too small");
+    return HEAT_CF_OK;
+}
 
 int heat_cf_device_count(void)
 {

@@ -116,6 +116,11 @@ typedef struct heat_cf_device_view
 
 int         heat_cf_abi_version(void);
 const char* heat_cf_last_error(void);
+/* Launch plan the engine would use for `cfg` — kernel variant, coherence, number of streams (asynchrony cap) and update
+ * policy — as a small JSON object written to `out`.  Pure host logic, no GPU needed; `resident_workgroups` is what the
+ * chip keeps resident for the variant (0 = unknown: only the caps apply). */
+int         heat_cf_plan(const heat_cf_config* cfg, uint64_t data_rows, uint64_t resident_workgroups, char* out,
+                         uint64_t out_bytes);
 /* number of visible HIP devices, or a negative error code */
 int         heat_cf_device_count(void);
 

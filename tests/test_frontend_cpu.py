@@ -208,3 +208,45 @@ def test_native_lightgcn_ingest_matches_the_reference_loop(tmp_path):
         abi.parse_lightgcn(str(bad))
     with pytest.raises(ValueError):
         abi.parse_lightgcn(str(tmp_path / "missing.txt"))
+
+
+def test_launch_plan_host_logic():
+    """heat_cf_plan (no GPU): kernel variant table, asynchrony cap and AUTO update policy."""
+    from heat_amd import abi
+    A = dict(emb_dim=64, num_negs=16, num_users=52643, num_items=91599, train_size=2380730)
+    p = abi.plan(resident_workgroups=256 * 12, **A)
+    assert (p["lanes_per_row"], p["groups_per_wave"], p["waves_per_workgroup"], p["negative_capacity"]) == (16, 4, 1, 16)
+    assert p["cap_items"] == int(0.56 * 91599 / 17) == 3017 and p["cap_users"] == int(0.058 * 52643)
+    assert p["streams"] == 3017 and p["update_mode"] == "ATOMIC_POS" and p["update_bits"] == 0xC and p["coherence"] == "device"
+    # fewer resident workgroups than the cap: the chip is the limit
+    assert abi.plan(resident_workgroups=1024, **A)["streams"] == 1024
+    # forcing many streams pushes the expected negative-row collisions past 0.56 -> every item row goes atomic
+    assert abi.plan(num_streams=8192, **A)["update_mode"] == "ATOMIC_WG"
+    assert abi.plan(num_streams=8192, update_mode=abi.UPDATE_ATOMIC_POS, **A)["update_bits"] == 0xC
+    assert abi.plan(flags=abi.FLAG_SERIAL, **A)["streams"] == 1
+    # plain (non-coherent) row traffic cannot use atomics
+    assert abi.plan(coherence=abi.COHERENCE_PLAIN, **A)["update_mode"] == "OVERWRITE"
+    with pytest.raises(ValueError):
+        abi.plan(coherence=abi.COHERENCE_PLAIN, update_mode=abi.UPDATE_ATOMIC_WG, **A)
+    # variant table: Yelp18 (d128, N64) -> 32 lanes/row, 8 groups x 4 waves; synthetic-HBM (d256, N100) -> 25 groups x 4 waves
+    y = abi.plan(emb_dim=128, num_negs=64, num_users=31668, num_items=38048, train_size=1237259)
+    assert (y["lanes_per_row"], y["groups_per_wave"], y["waves_per_workgroup"], y["streams"]) == (32, 8, 4, 327)
+    s_ = abi.plan(emb_dim=256, num_negs=100, num_users=10_000_000, num_items=1_000_000, train_size=200_000_000,
+                  resident_workgroups=256)
+    assert (s_["lanes_per_row"], s_["groups_per_wave"], s_["waves_per_workgroup"], s_["streams"]) == (64, 25, 4, 256)
+    # masked shapes: emb_dim 20 -> 8 lanes/row (5 used); 5 negatives -> 1 group of 8 rows
+    m = abi.plan(emb_dim=20, num_negs=5, num_users=100, num_items=1000, train_size=10)
+    assert (m["lanes_per_row"], m["negative_capacity"]) == (8, 8)
+    # the aggregator is built for single-wave variants
+    assert abi.plan(emb_dim=128, num_negs=64, num_users=31668, num_items=38048, train_size=10,
+                    use_aggregator=True)["waves_per_workgroup"] == 1
+    # outside the compiled family
+    for bad in (dict(emb_dim=6), dict(emb_dim=260), dict(num_negs=500)):
+        cfg = dict(emb_dim=64, num_negs=16, num_users=10, num_items=10, train_size=1)
+        cfg.update(bad)
+        with pytest.raises(abi.HeatError):
+            abi.plan(**cfg)
+    with pytest.raises(ValueError):
+        abi.plan(emb_dim=64, num_negs=0, num_users=10, num_items=10, train_size=1)
+    with pytest.raises(ValueError):
+        abi.plan(emb_dim=64, num_negs=4, num_users=10, num_items=10, train_size=1, milestones=())
