@@ -445,3 +445,34 @@ def test_windows_compose_to_the_whole_range():
         outs.append((a, b, loss))
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
     assert abs(outs[0][2] - outs[1][2]) < 1e-9 * abs(outs[0][2])
+
+
+def test_randomized_serial_parity_sweep():
+    """40 random configurations (emb_dim multiple of 4 up to 256, 1..100 negatives, every update policy, both samplers'
+    id ranges, ragged lengths): the serial GPU walk vs the oracle on caller-fed negatives, duplicates and negative ==
+    positive collisions included.  Catches variant-specific indexing errors (masked lanes / slots, multi-wave
+    workgroups, atomics vs stores)."""
+    rng = np.random.default_rng(2024)
+    modes = [abi.UPDATE_OVERWRITE, abi.UPDATE_ATOMIC_W, abi.UPDATE_ATOMIC_WG, abi.UPDATE_ATOMIC_POS, abi.UPDATE_AUTO]
+    for case in range(40):
+        d = int(rng.choice([4, 8, 12, 20, 32, 48, 64, 96, 128, 160, 256]))
+        N = int(rng.choice([1, 2, 3, 5, 8, 16, 17, 31, 32, 50, 64, 100]))
+        U = int(rng.integers(2, 12))
+        I = int(rng.integers(max(3, N // 4), 400))
+        T = int(rng.integers(1, 150))
+        mode = modes[case % len(modes)]
+        clicks = np.stack([np.sort(rng.integers(0, U, T)), rng.integers(0, I, T)], axis=1).astype(np.uint64)
+        uw = (rng.standard_normal((U, d)) * 0.1).astype(np.float32)
+        iw = (rng.standard_normal((I, d)) * 0.1).astype(np.float32)
+        negs = rng.integers(0, I, size=(T, N)).astype(np.uint64)
+        ug, ig, uo, io = uw.copy(), iw.copy(), uw.copy(), iw.copy()
+        eng = abi.Engine(clicks, ug, ig, num_negs=N, flags=abi.FLAG_SERIAL, update_mode=mode, clip_val=0.5, l_r=0.01)
+        lg = eng.train_range(0, T, negs)
+        eng.sync_to_host()
+        name = eng.kernel_name
+        eng.close()
+        lo = orc.Engine(clicks, uo, io, num_negs=N, clip_val=0.5, l_r=0.01).train_range(0, T, negs)
+        ctx = f"case {case}: d={d} N={N} U={U} I={I} T={T} mode={mode} {name}"
+        assert abs(lg - lo) <= 2e-5 * max(1.0, abs(lo)), ctx
+        assert np.abs(ug - uo).max() <= 3e-4 * np.abs(uo).max(), ctx
+        assert np.abs(ig - io).max() <= 3e-4 * np.abs(io).max(), ctx
