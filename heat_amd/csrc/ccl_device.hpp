@@ -50,6 +50,38 @@ __device__ __forceinline__ float row_sum(float x)
 }
 
 // Reductions across the R = 64/LPR row groups of a wave (lanes l, l^LPR, l^2LPR, ...).
+// gfx950 has v_permlane16_swap / v_permlane32_swap (VALU, no LDS crossbar round trip): swap(x, x) leaves
+// {rows 0,0,2,2} in one register and {rows 1,1,3,3} in the other, so their sum / max is the xor-16 butterfly step.
+#ifdef HEATCF_PERMLANE
+__device__ __forceinline__ void swap16(float x, float& a, float& b)
+{
+    a = x; b = x;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ void swap32(float x, float& a, float& b)
+{
+    a = x; b = x;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+}
+template <int LPR>
+__device__ __forceinline__ float cross_sum(float x)
+{
+    float a, b;
+    if (LPR <= 8) x += lane_xor(x, 8);
+    if (LPR <= 16) { swap16(x, a, b); x = a + b; }
+    if (LPR <= 32) { swap32(x, a, b); x = a + b; }
+    return x;
+}
+template <int LPR>
+__device__ __forceinline__ float cross_max(float x)
+{
+    float a, b;
+    if (LPR <= 8) x = fmaxf(x, lane_xor(x, 8));
+    if (LPR <= 16) { swap16(x, a, b); x = fmaxf(a, b); }
+    if (LPR <= 32) { swap32(x, a, b); x = fmaxf(a, b); }
+    return x;
+}
+#else
 template <int LPR>
 __device__ __forceinline__ float cross_sum(float x)
 {
@@ -64,19 +96,26 @@ __device__ __forceinline__ float cross_max(float x)
     for (int m = LPR; m < 64; m <<= 1) x = fmaxf(x, lane_xor(x, m));
     return x;
 }
+#endif
 
 __device__ __forceinline__ float dot4(f32x4 a, f32x4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
 
 __device__ __forceinline__ f32x4 clip4(f32x4 g, float c)
 {
-    // optimizers/optimizer.cpp:17-22: max(min(g, c), -c)
+    // optimizers/optimizer.cpp:17-22: max(min(g, c), -c) == median(g, -c, c) for c >= 0: one v_med3_f32 per element
     f32x4 r;
-    r.x = fmaxf(fminf(g.x, c), -c);
-    r.y = fmaxf(fminf(g.y, c), -c);
-    r.z = fmaxf(fminf(g.z, c), -c);
-    r.w = fmaxf(fminf(g.w, c), -c);
+    r.x = __builtin_amdgcn_fmed3f(g.x, -c, c);
+    r.y = __builtin_amdgcn_fmed3f(g.y, -c, c);
+    r.z = __builtin_amdgcn_fmed3f(g.z, -c, c);
+    r.w = __builtin_amdgcn_fmed3f(g.w, -c, c);
     return r;
 }
+
+// 1/x and sqrt(x) as single hardware instructions (v_rcp_f32 / v_sqrt_f32, 1 ulp) instead of the ~10-instruction
+// correctly rounded sequences: the kernel evaluates 19 divisions and 6 square roots per interaction, all on values that
+// are clamped away from 0 (eps = 1e-8) and far from the denormal range.  The difference to IEEE division is <= 2 ulp.
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 
 // ---- buffer (SRD) access with cache policy ---------------------------------------------------------------
 // An out-of-range byte offset makes a raw buffer load return 0 and a store be dropped: masked lanes simply
@@ -110,8 +149,13 @@ __device__ __forceinline__ uint64_t philox_draw64(uint32_t slot, uint64_t idx, u
 {
     uint32_t c0 = slot, c1 = 0u, c2 = (uint32_t)idx, c3 = (uint32_t)(idx >> 32);
     uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#ifdef HEATCF_EXP_CHEAP_RNG
+    constexpr int ROUNDS = 1; // development builds only: how much do the Philox rounds cost?
+#else
+    constexpr int ROUNDS = 10;
+#endif
 #pragma unroll
-    for (int r = 0; r < 10; ++r)
+    for (int r = 0; r < ROUNDS; ++r)
     {
         const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
         const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;

@@ -78,6 +78,21 @@ __device__ __forceinline__ void atomic_add_tile(__amdgpu_buffer_rsrc_t rsrc, con
         __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(tile[q * 64 + lane], rsrc, (int)ao.o[q], 0, 0);
 }
 
+// does any other lane of my 16-lane DPP row hold the same id?  (row_ror:1..15)
+template <int ROT>
+__device__ __forceinline__ void dup_rot_step(uint32_t id, bool& hit)
+{
+    const uint32_t other = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)id, 0x120 + ROT, 0xF, 0xF, true);
+    hit = hit || (other == id);
+}
+__device__ __forceinline__ void dup_rotations(uint32_t id, bool& hit)
+{
+    dup_rot_step<1>(id, hit);  dup_rot_step<2>(id, hit);  dup_rot_step<3>(id, hit);  dup_rot_step<4>(id, hit);
+    dup_rot_step<5>(id, hit);  dup_rot_step<6>(id, hit);  dup_rot_step<7>(id, hit);  dup_rot_step<8>(id, hit);
+    dup_rot_step<9>(id, hit);  dup_rot_step<10>(id, hit); dup_rot_step<11>(id, hit); dup_rot_step<12>(id, hit);
+    dup_rot_step<13>(id, hit); dup_rot_step<14>(id, hit); dup_rot_step<15>(id, hit);
+}
+
 template <int LPR, int AUX>
 __device__ __forceinline__ void flush_user_row(const TrainArgs& a, uint32_t user, bool cut, f32x4 u4, f32x4 gu4, f32x4 u4_in,
                                                f32x4 gu4_in, float* tile, int lane, int rr, bool col_ok, uint32_t col_off)
@@ -198,6 +213,7 @@ __global__ __launch_bounds__(64 * NW) HEATCF_OCC void ccl_train_kernel(TrainArgs
 #pragma unroll
     for (int v = 0; v < NIDV; ++v) nid[v] = 0u; // engine.cpp:298: neg_ids zero-initialised per worker
     double loss_acc = 0.0;
+    uint32_t raw_batch = 0u;               // raw draws of up to four interactions (BATCH4)
 
     for (uint64_t base = first; base < last; base += 64)
     {
@@ -221,6 +237,27 @@ __global__ __launch_bounds__(64 * NW) HEATCF_OCC void ccl_train_kernel(TrainArgs
             }
 
             // ---- negatives: lane k, register v owns slot wave_base + v*64 + k --------------------------------
+            // Single-wave variants with <= 16 slots draw FOUR interactions per Philox evaluation: lane l computes slot
+            // (l & 15) of interaction idx + (l >> 4); the same (slot, interaction index) counter as always, so the ids
+            // are unchanged — 3 of 4 interactions skip the ~95-instruction generator.
+            constexpr bool BATCH4 = (NW == 1 && WCAP <= 16 && NIDV == 1);
+            if (BATCH4 && a.ext_negs == nullptr)
+            {
+                if ((j & 3) == 0)
+                {
+                    const uint64_t bidx = a.sample_base + idx + (uint64_t)(lane >> 4);
+                    if (a.tile_size != 0u && a.sampling_call)
+                        raw_batch = tile_item((uint32_t)(lane & 15), bidx, a.key, blockIdx.x, idx + (uint64_t)(lane >> 4) - first,
+                                              a.tile_size, a.refresh_interval, a.num_items);
+                    else
+                        raw_batch = uniform_item(philox_draw64((uint32_t)(lane & 15), bidx, a.key), a.num_items);
+                }
+                uint32_t id = lane_get(raw_batch, ((j & 3) << 4) | (lane & 15));
+                if (!a.sampling_call && id == pos) id = nid[0];      // ignore_pos_sampling: keep the previous id
+                nid[0] = id;
+                if (a.neg_out != nullptr && (uint32_t)lane < N) a.neg_out[(idx - a.neg_out_base) * N + (uint32_t)lane] = id;
+            }
+            else
 #pragma unroll
             for (int v = 0; v < NIDV; ++v)
             {
@@ -340,7 +377,18 @@ __global__ __launch_bounds__(64 * NW) HEATCF_OCC void ccl_train_kernel(TrainArgs
 #pragma unroll
                 for (int v = 0; v < NIDV; ++v) { eq[v] = 0u; earlier[v] = 0u; }
                 if (NW > 1) __syncthreads();                 // B1: every wave's ids are in sh_ids
-                for (uint32_t s = 0; s < N; ++s)
+                // Fast rejection when the interaction's N <= 16 slots sit in one 16-lane DPP row (lanes 0..15 of a
+                // single-wave variant): 15 row rotations compare every pair; the counting scan below only runs when a
+                // duplicate exists (0.14 % of the interactions at AmazonBooks shape).
+                bool need_scan = true;
+                if (NW == 1 && WCAP <= 16)
+                {
+                    const uint32_t mine = (uint32_t)lane < N ? nid[0] : 0xFFFFFF00u + (uint32_t)lane; // unique sentinels
+                    bool hit = false;
+                    dup_rotations(mine, hit);
+                    need_scan = __builtin_amdgcn_ballot_w64(hit && lane < 16) != 0ull;
+                }
+                for (uint32_t s = 0; need_scan && s < N; ++s)
                 {
                     uint32_t sid = 0u;
                     if (NW > 1)
@@ -384,13 +432,13 @@ __global__ __launch_bounds__(64 * NW) HEATCF_OCC void ccl_train_kernel(TrainArgs
             const float uu = row_sum<LPR>(dot4(u4, u4));
             const float pp = row_sum<LPR>(dot4(p4, p4));
             const float up = row_sum<LPR>(dot4(u4, p4));
-            const float unorm = sqrtf(fmaxf(uu, eps));
-            const float pnorm = sqrtf(fmaxf(pp, eps));
+            const float unorm = fast_sqrt(fmaxf(uu, eps));
+            const float pnorm = fast_sqrt(fmaxf(pp, eps));
             const float unorm3 = unorm * unorm * unorm;
             const float pnorm3 = pnorm * pnorm * pnorm;
-            const float r_u3_p = 1.0f / (unorm3 * pnorm);
-            const float r_u_p3 = 1.0f / (unorm * pnorm3);
-            const float upcos = up / (unorm * pnorm);
+            const float r_u3_p = fast_rcp(unorm3 * pnorm);
+            const float r_u_p3 = fast_rcp(unorm * pnorm3);
+            const float upcos = up * fast_rcp(unorm * pnorm);
 
             float un[NGW], nn[NGW], es[NGW];
             float mx = -INFINITY;
@@ -399,8 +447,8 @@ __global__ __launch_bounds__(64 * NW) HEATCF_OCC void ccl_train_kernel(TrainArgs
             {
                 un[g] = row_sum<LPR>(dot4(u4, n4[g]));
                 nn[g] = row_sum<LPR>(dot4(n4[g], n4[g]));
-                const float nnorm = sqrtf(nn[g] < eps ? eps : nn[g]);
-                const float c = un[g] / (unorm * nnorm);
+                const float nnorm = fast_sqrt(nn[g] < eps ? eps : nn[g]);
+                const float c = un[g] * fast_rcp(unorm * nnorm);
                 const bool valid = wave_base + (uint32_t)(g * R + rr) < N;
                 es[g] = valid ? (c - upcos) * score_mul : -INFINITY;    // the score; becomes exp(score - max) below
                 mx = fmaxf(mx, es[g]);
@@ -431,6 +479,7 @@ __global__ __launch_bounds__(64 * NW) HEATCF_OCC void ccl_train_kernel(TrainArgs
             }
             // :106 adds exp(-max) computed in double; fp32 expf differs by <= 1 ulp of the sum
             const float Z = ssum + expf(-mx);
+            const float rcp_z = fast_rcp(Z);
             const float loss = mx + logf(Z);
             loss_acc += (double)loss;
 
@@ -448,11 +497,11 @@ __global__ __launch_bounds__(64 * NW) HEATCF_OCC void ccl_train_kernel(TrainArgs
             {
                 const f32x4 g_read = gpf[g % GPF];
                 if (g + GPF < NGW) gpf[g % GPF] = buf_load<AUX>(item_g, noff[g + GPF]);
-                const float lg = (es[g] / Z) * score_mul;                       // :109
-                const float nnorm = sqrtf(nn[g] < eps ? eps : nn[g]);
+                const float lg = (es[g] * rcp_z) * score_mul;                   // :109
+                const float nnorm = fast_sqrt(nn[g] < eps ? eps : nn[g]);
                 const float nnorm3 = nnorm * nnorm * nnorm;
-                const float r_u3_n = 1.0f / (unorm3 * nnorm);                   // :136
-                const float r_u_n3 = 1.0f / (unorm * nnorm3);                   // :137
+                const float r_u3_n = fast_rcp(unorm3 * nnorm);                  // :136
+                const float r_u_n3 = fast_rcp(unorm * nnorm3);                  // :137
                 const f32x4 unu = (uu * n4[g] - un[g] * u4) * r_u3_n;           // :138
                 const f32x4 unn = (nn[g] * u4 - un[g] * n4[g]) * r_u_n3;        // :139 (raw nn, not eps-clamped)
                 gu_acc += lg * (unu - upu);                                     // :141
@@ -539,7 +588,7 @@ __global__ __launch_bounds__(64 * NW) HEATCF_OCC void ccl_train_kernel(TrainArgs
                             const f32x4 fg = *reinterpret_cast<const f32x4*>(agg_pairs + (c * 2 + 1) * DP + sub * 4);
                             acc += m * fg;
                         }
-                        const f32x4 delta = -(a.agg_lr * (acc / 32.0f));             // :143-144
+                        const f32x4 delta = -(a.agg_lr * (acc * 0.03125f));          // :143-144 (/32 is exact as *2^-5)
                         const uint32_t off = (i < D && col_ok) ? (uint32_t)(i * D * 4) + col_off : OOB_OFF;
                         const AtomicOffsets ao = atomic_offsets(off, lane);
                         atomic_add_tile<4>(w0r, ao, delta, tile, lane);
