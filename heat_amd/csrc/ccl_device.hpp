@@ -50,38 +50,6 @@ __device__ __forceinline__ float row_sum(float x)
 }
 
 // Reductions across the R = 64/LPR row groups of a wave (lanes l, l^LPR, l^2LPR, ...).
-// gfx950 has v_permlane16_swap / v_permlane32_swap (VALU, no LDS crossbar round trip): swap(x, x) leaves
-// {rows 0,0,2,2} in one register and {rows 1,1,3,3} in the other, so their sum / max is the xor-16 butterfly step.
-#ifdef HEATCF_PERMLANE
-__device__ __forceinline__ void swap16(float x, float& a, float& b)
-{
-    a = x; b = x;
-    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
-}
-__device__ __forceinline__ void swap32(float x, float& a, float& b)
-{
-    a = x; b = x;
-    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
-}
-template <int LPR>
-__device__ __forceinline__ float cross_sum(float x)
-{
-    float a, b;
-    if (LPR <= 8) x += lane_xor(x, 8);
-    if (LPR <= 16) { swap16(x, a, b); x = a + b; }
-    if (LPR <= 32) { swap32(x, a, b); x = a + b; }
-    return x;
-}
-template <int LPR>
-__device__ __forceinline__ float cross_max(float x)
-{
-    float a, b;
-    if (LPR <= 8) x = fmaxf(x, lane_xor(x, 8));
-    if (LPR <= 16) { swap16(x, a, b); x = fmaxf(a, b); }
-    if (LPR <= 32) { swap32(x, a, b); x = fmaxf(a, b); }
-    return x;
-}
-#else
 template <int LPR>
 __device__ __forceinline__ float cross_sum(float x)
 {
@@ -96,7 +64,6 @@ __device__ __forceinline__ float cross_max(float x)
     for (int m = LPR; m < 64; m <<= 1) x = fmaxf(x, lane_xor(x, m));
     return x;
 }
-#endif
 
 __device__ __forceinline__ float dot4(f32x4 a, f32x4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
 
@@ -149,11 +116,7 @@ __device__ __forceinline__ uint64_t philox_draw64(uint32_t slot, uint64_t idx, u
 {
     uint32_t c0 = slot, c1 = 0u, c2 = (uint32_t)idx, c3 = (uint32_t)(idx >> 32);
     uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-#ifdef HEATCF_EXP_CHEAP_RNG
-    constexpr int ROUNDS = 1; // development builds only: how much do the Philox rounds cost?
-#else
     constexpr int ROUNDS = 10;
-#endif
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r)
     {

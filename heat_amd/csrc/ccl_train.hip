@@ -130,13 +130,8 @@ __device__ __forceinline__ void flush_user_row(const TrainArgs& a, uint32_t user
 // applied every 32 calls (W0 -= lr * acc/32, here by float atomic adds on the shared W0), and g_u *= 0.4.
 // The stream keeps a private LDS copy of W0 (refreshed after each of its own W0 updates) and the last <= 32
 // (means, 0.6 g_u) pairs; the accumulation order of the reference (call by call) is preserved when the pairs are summed.
-#ifdef HEATCF_WAVES_PER_EU
-#define HEATCF_OCC __attribute__((amdgpu_waves_per_eu(HEATCF_WAVES_PER_EU, HEATCF_WAVES_PER_EU)))
-#else
-#define HEATCF_OCC
-#endif
 template <int LPR, int NGW, int AUX, int NW, bool AGG>
-__global__ __launch_bounds__(64 * NW) HEATCF_OCC void ccl_train_kernel(TrainArgs a)
+__global__ __launch_bounds__(64 * NW) void ccl_train_kernel(TrainArgs a)
 {
     static_assert(!AGG || NW == 1, "behaviour aggregation is built for single-wave workgroups");
     const bool neg_w_atomic = (a.upd_bits & 1u) != 0u, neg_g_atomic = (a.upd_bits & 2u) != 0u;
@@ -148,10 +143,7 @@ __global__ __launch_bounds__(64 * NW) HEATCF_OCC void ccl_train_kernel(TrainArgs
     // how many groups ahead the G rows are fetched in the backward sweep: a short look-ahead keeps the read-modify-write
     // window of a negative's G row small (fewer Hogwild collisions) where rows are small and hot; the multi-wave
     // variants (large rows, large tables) fetch deep to cover HBM latency
-#ifndef HEATCF_GPF1
-#define HEATCF_GPF1 4
-#endif
-    constexpr int GPF = NW > 1 ? (NGW < 16 ? NGW : 16) : (HEATCF_GPF1 < NGW ? HEATCF_GPF1 : NGW);
+    constexpr int GPF = NW > 1 ? (NGW < 16 ? NGW : 16) : (NGW < 4 ? NGW : 4);
     const int lane = (int)(threadIdx.x & 63u);
     const int wave = NW == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t wave_base = (uint32_t)(wave * WCAP);
@@ -539,9 +531,7 @@ __global__ __launch_bounds__(64 * NW) HEATCF_OCC void ccl_train_kernel(TrainArgs
                     if (neg_g_atomic) atomic_add_tile<4>(item_g, ao, gn - g_read, tile, lane);
                     else buf_store<AUX>(item_g, woff, gn);
                 }
-#ifndef HEATCF_NO_SCHED_BARRIER
                 if ((g % GPF) == GPF - 1) __builtin_amdgcn_sched_barrier(0);    // bound how far G fetches are hoisted
-#endif
             }
             gu_acc.x = cross_sum<LPR>(gu_acc.x);
             gu_acc.y = cross_sum<LPR>(gu_acc.y);
@@ -723,15 +713,11 @@ static hipError_t launch_variant(const TrainArgs& a, uint32_t grid, int aux, hip
 // (lanes per row, register groups per wave, waves per workgroup): capacity = NGW * (64/LPR) * NW negatives.
 // Per-wave register budget ~ 8 VGPRs per group + ~60; more waves per workgroup instead of more groups per wave once a
 // wave would need > ~20 groups.
-#ifdef HEATCF_ONLY_A
-#define HEATCF_VARIANTS(X) X(16, 4, 1)
-#else
 #define HEATCF_VARIANTS(X) \
     X(8, 1, 1) X(8, 2, 1) X(8, 4, 1) X(8, 8, 1) X(8, 16, 1) \
     X(16, 2, 1) X(16, 4, 1) X(16, 8, 1) X(16, 16, 1) X(16, 16, 2) \
     X(32, 4, 1) X(32, 8, 1) X(32, 16, 1) X(32, 32, 1) X(32, 16, 2) X(32, 8, 4) X(32, 16, 4) \
     X(64, 8, 1) X(64, 16, 1) X(64, 16, 2) X(64, 16, 4) X(64, 25, 4) X(64, 13, 8) X(64, 16, 8)
-#endif
 
 bool pick_variant(uint32_t emb_dim, uint32_t num_negs, bool single_wave, int* lpr_out, int* ng_out, int* nw_out)
 {
