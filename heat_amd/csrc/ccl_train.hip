@@ -445,6 +445,11 @@ __global__ __launch_bounds__(64 * NW) void ccl_train_kernel(TrainArgs a)
                 es[g] = valid ? (c - upcos) * score_mul : -INFINITY;    // the score; becomes exp(score - max) below
                 mx = fmaxf(mx, es[g]);
             }
+            // the first G rows are requested here, so that their latency overlaps the softmax arithmetic; the rest follow
+            // GPF groups ahead of their use in the backward sweep
+            f32x4 gpf[GPF];                                             // G rows in flight
+#pragma unroll
+            for (int g = 0; g < GPF && g < NGW; ++g) gpf[g] = buf_load<AUX>(item_g, noff[g]);
             mx = cross_max<LPR>(mx);
             if (NW > 1)
             {
@@ -481,9 +486,6 @@ __global__ __launch_bounds__(64 * NW) void ccl_train_kernel(TrainArgs a)
             const f32x4 upp = -(pp * u4 - up * p4) * r_u_p3;
             f32x4 gu_acc = {0, 0, 0, 0};
             float slg = 0.0f;
-            f32x4 gpf[GPF];                                             // G rows in flight
-#pragma unroll
-            for (int g = 0; g < GPF && g < NGW; ++g) gpf[g] = buf_load<AUX>(item_g, noff[g]);
 #pragma unroll
             for (int g = 0; g < NGW; ++g)
             {
