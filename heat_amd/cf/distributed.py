@@ -29,6 +29,8 @@ def shard_clicks(clicks, num_users, world_size, rank):
     """Interactions of the rank's users with user ids re-based to the shard (cf/datasets.py:120-137)."""
     lo, hi = shard_bounds(num_users, world_size, rank)
     u = clicks[:, 0]
+    if u.size > 1 and np.any(u[1:] < u[:-1]):
+        raise ValueError("the interaction list must be grouped by ascending user id (LightGCN order) to be sharded by user range")
     a, b = np.searchsorted(u, lo, side="left"), np.searchsorted(u, hi, side="left")
     out = clicks[a:b].copy()
     out[:, 0] -= np.uint64(lo)
@@ -55,6 +57,7 @@ class ItemSync:
         self.force = bool(force_collective)     # run the collective path even with one rank (tests)
         self.ref = item_w.clone() if (mode == "sum" and (world_size > 1 or self.force)) else None
         self._n_max = None
+        self.track_loss = False   # True: train_range synchronises per window and the local loss sum is returned
         if mode not in ("sum", "mean"):
             raise ValueError("mode must be 'sum' or 'mean'")
 
@@ -91,10 +94,92 @@ class ItemSync:
         window = min(self.window, max(1, n_max))
         n_windows = max(1, -(-n_max // window))
         e.begin_epoch()
+        loss_sum = 0.0
         for w in range(n_windows):
             lo = min(n, w * window)
             hi = min(n, (w + 1) * window)
             if hi > lo:
-                e.train_range(lo, hi, want_loss=False)
+                got = e.train_range(lo, hi, want_loss=self.track_loss)
+                if self.track_loss:
+                    loss_sum += got
             self.sync()
         e.end_epoch()
+        return loss_sum if self.track_loss else None
+
+
+class ShardedTrainer:
+    """One rank of a user-sharded training job (the fork's intent at cf/main.py:47-70 + engine.cpp:366-375, without
+    MPI): takes the WHOLE interaction list and the WHOLE initial tables (identical on every rank), keeps only this
+    rank's users, builds a device-mode engine on torch tensors and synchronises the replicated item table with ItemSync.
+
+        trainer = ShardedTrainer(clicks, user_w, item_w, num_negs=16, seed=2022)      # after init_process_group
+        for epoch in range(E): trainer.train_one_epoch()
+        user_w_shard, item_w = trainer.weights()           # numpy; users [lo, hi) of this rank
+
+    `engine_factory(shard_clicks, user_w_shard_tensor, item_w_tensor, sample_index_base)` may replace the HIP engine
+    (the CPU tests plug the oracle in that way)."""
+
+    def __init__(self, clicks, user_w, item_w, *, num_negs, rank=None, world_size=None, device=None, seed=2022,
+                 refresh_interval=8192, sync_interactions=0, mode="sum", engine_factory=None, **cfg_kwargs):
+        import torch
+        import torch.distributed as dist
+        self.torch = torch
+        self.rank = dist.get_rank() if rank is None else rank
+        self.world = dist.get_world_size() if world_size is None else world_size
+        num_users = user_w.shape[0]
+        self.num_users_total = num_users
+        self.shard, self.lo, self.hi = shard_clicks(clicks, num_users, self.world, self.rank)
+        base = int(np.searchsorted(clicks[:, 0], self.lo, side="left"))      # global index of the shard's first interaction
+        if engine_factory is None:
+            from heat_amd import abi
+            dev = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+            self.t_clicks = torch.from_numpy(self.shard.view(np.int64)).to(dev)
+            self.t_user = torch.from_numpy(np.ascontiguousarray(user_w[self.lo:self.hi])).to(dev)
+            self.t_item = torch.from_numpy(np.ascontiguousarray(item_w)).to(dev)
+            stream = torch.cuda.current_stream().cuda_stream
+            flags = cfg_kwargs.pop("flags", 0) | (0 if stream else abi.FLAG_NULL_STREAM)
+            self.engine = abi.Engine.from_device(
+                self.t_clicks.data_ptr(), self.shard.shape[0], self.t_user.data_ptr(), self.t_item.data_ptr(),
+                num_users=self.hi - self.lo, num_items=item_w.shape[0], emb_dim=item_w.shape[1], num_negs=num_negs,
+                stream=stream or None, seed=seed, sample_index_base=base, flags=flags, device=dev.index,
+                keep=(self.t_clicks, self.t_user, self.t_item), **cfg_kwargs)
+        else:
+            self.t_user = torch.from_numpy(np.ascontiguousarray(user_w[self.lo:self.hi]).copy())
+            self.t_item = torch.from_numpy(np.ascontiguousarray(item_w).copy())
+            self.engine = engine_factory(self.shard, self.t_user, self.t_item, base)
+        self.sync = ItemSync(self.engine, self.t_item, self.world, refresh_interval=refresh_interval,
+                             sync_interactions=sync_interactions, mode=mode)
+
+    def train_one_epoch(self, want_loss=False):
+        """One epoch on this rank's shard.  want_loss=True returns the GLOBAL mean loss (loss sums and interaction counts
+        summed over ranks, train/engine.cpp:380-385)."""
+        self.sync.track_loss = bool(want_loss)
+        local = self.sync.train_one_epoch()
+        if not want_loss:
+            return None
+        import torch.distributed as dist
+        t = self.torch.tensor([local, float(self.shard.shape[0])], dtype=self.torch.float64, device=self.t_item.device)
+        if self.world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return float(t[0].item() / max(t[1].item(), 1.0))
+
+    def weights(self):
+        """(this rank's user rows [lo, hi), the replicated item table) as numpy arrays."""
+        if self.t_item.is_cuda:
+            self.torch.cuda.current_stream().synchronize()
+        return self.t_user.cpu().numpy(), self.t_item.cpu().numpy()
+
+    def gather_user_weights(self):
+        """The full user table on every rank (all_gather of the shards; shards differ by at most one row)."""
+        import torch.distributed as dist
+        if self.world == 1:
+            return self.t_user.cpu().numpy()
+        torch = self.torch
+        d = self.t_user.shape[1]
+        rows = [b - a for a, b in (shard_bounds(self.num_users_total, self.world, r) for r in range(self.world))]
+        pad = max(rows)
+        mine = torch.zeros((pad, d), dtype=self.t_user.dtype, device=self.t_user.device)
+        mine[:self.t_user.shape[0]] = self.t_user
+        parts = [torch.empty_like(mine) for _ in range(self.world)]
+        dist.all_gather(parts, mine)
+        return torch.cat([p[:n] for p, n in zip(parts, rows)]).cpu().numpy()

@@ -29,6 +29,49 @@ def _graph_to_datasets(graph, cf_config, seed):
     return train, test
 
 
+def _main_distributed(args, model_config, cf_config, train_data, test_data, seed):
+    """torchrun path (one process per GPU): users sharded by contiguous range, item table replicated and synchronised by
+    heat_amd.cf.distributed — what the fork does with mpi4py + per-row MPI collectives (cf/main.py:47-97, engine.cpp:262-375)."""
+    import torch.distributed as dist
+    from .distributed import ShardedTrainer
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    rank, world = dist.get_rank(), dist.get_world_size()
+    model = MatrixFactorization(cf_config)                      # identical initial tables on every rank (same torch seed)
+    user_w = model.user_embedding.weight.detach().cpu().numpy()
+    item_w = model.item_embedding.weight.detach().cpu().numpy()
+    trainer = ShardedTrainer(train_data.click_dataset, user_w, item_w, num_negs=cf_config.num_negs, seed=seed,
+                             clip_val=cf_config.clip_val, l_r=cf_config.l_r, milestones=tuple(cf_config.milestones),
+                             refresh_interval=cf_config.refresh_interval, neg_sampler=cf_config.neg_sampler,
+                             tile_size=cf_config.tile_size)
+    lo, hi = trainer.lo, trainer.hi
+    indptr, items = train_data.train_csr()
+    local_indptr = (indptr[lo:hi + 1] - indptr[lo]).astype(np.uint64)
+    local_items = items[int(indptr[lo]):int(indptr[hi])]
+    results = {}
+    for epoch in range(model_config['epochs']):
+        start_time = time.time()
+        epoch_loss = trainer.train_one_epoch(want_loss=True)
+        if rank == 0:
+            print(f'epoch: {epoch}; loss: {epoch_loss}; epoch_time: {time.time() - start_time}')
+        if epoch > 0 and epoch % model_config['eval_interval'] == 0:
+            top = trainer.engine.topk(20, mask_indptr=local_indptr, mask_items=local_items)     # this rank's users
+            local_test = {u - lo: v for u, v in test_data.user_items_dic.items() if lo <= u < hi}
+            sums = torch.zeros(2, dtype=torch.float64, device=torch.device("cuda", local_rank))
+            if local_test:
+                r = metrics.evaluate_topk(type("T", (), {"user_items_dic": local_test})(), top, ['Recall(k=20)'], quiet=True,
+                                          by_user_id=True)
+                sums[0], sums[1] = r['Recall(k=20)'] * len(local_test), len(local_test)
+            dist.all_reduce(sums)
+            results = {'Recall(k=20)': float(sums[0] / sums[1].clamp(min=1))}
+            if rank == 0:
+                print('[Metrics] Recall(k=20): {:.6f}'.format(results['Recall(k=20)']))
+    dist.barrier()
+    dist.destroy_process_group()
+    return results
+
+
 def main(argv=None):
     print('this is main ...')
     parser = argparse.ArgumentParser()
@@ -36,6 +79,7 @@ def main(argv=None):
                                                                    'MF_CCL', 'configs', 'config0.yaml'))
     parser.add_argument('--synthetic', type=str, default=None, help='amazonbooks | gowalla | yelp18: seeded synthetic graph')
     parser.add_argument('--scale', type=float, default=1.0)
+    parser.add_argument('--distributed', action='store_true', help='use the sharded multi-GPU trainer even with one rank')
     parser.add_argument('--gpu-topk', action='store_true', help='evaluate with the fused GPU top-k instead of evaluate0()')
     args = parser.parse_args(argv)
     config_dic = utils.load_config(args.config)
@@ -60,6 +104,8 @@ def main(argv=None):
         train_data = ClickDataset(train_file, separator=dataset_config['separator'], config=cf_config, seed=seed)
         test_data = ClickDataset(test_file, separator=dataset_config['separator'], config=cf_config, seed=seed)
     print('--- Finished loading data ---')
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 or args.distributed:
+        return _main_distributed(args, model_config, cf_config, train_data, test_data, seed)
     cf_config.init_c_instance()
     aggregator_weights = AggregatorWeights(cf_config)
     model = MatrixFactorization(cf_config)

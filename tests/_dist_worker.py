@@ -10,7 +10,7 @@ import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from heat_amd.cf.distributed import ItemSync, shard_clicks  # noqa: E402
+from heat_amd.cf.distributed import ShardedTrainer  # noqa: E402
 from oracle import cf_oracle as orc  # noqa: E402
 
 
@@ -39,17 +39,19 @@ def main():
     rank, world = dist.get_rank(), dist.get_world_size()
     data = np.load(os.path.join(out_dir, "problem.npz"))
     clicks, num_users = data["clicks"], int(data["num_users"])
-    shard, lo, hi = shard_clicks(clicks, num_users, world, rank)
-    a = int(np.searchsorted(clicks[:, 0], lo))
-    negs = data["negs"][a:a + shard.shape[0]]
-    uw = data["uw"][lo:hi].copy()
-    iw = data["iw"].copy()
-    item_t = torch.from_numpy(iw)          # shares memory with the oracle's borrowed table
-    eng = OracleWindows(shard, uw, iw, negs, int(data["num_negs"]), float(data["lr"]))
-    sync = ItemSync(eng, item_t, world, sync_interactions=window, mode=mode)
+    all_negs, N, lr = data["negs"], int(data["num_negs"]), float(data["lr"])
+
+    def oracle_factory(shard, t_user, t_item, base):
+        # the tensors share memory with the numpy views the oracle borrows and trains in place
+        return OracleWindows(shard, t_user.numpy(), t_item.numpy(), all_negs[base:base + shard.shape[0]], N, lr)
+
+    tr = ShardedTrainer(clicks, data["uw"], data["iw"], num_negs=N, sync_interactions=window, mode=mode,
+                        engine_factory=oracle_factory)
     for _ in range(int(data["epochs"])):
-        sync.train_one_epoch()
-    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), uw=uw, iw=iw, lo=lo, hi=hi, rows=shard.shape[0])
+        tr.train_one_epoch()
+    uw, iw = tr.weights()
+    full_u = tr.gather_user_weights()
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), uw=uw, iw=iw, lo=tr.lo, hi=tr.hi, rows=tr.shard.shape[0], full_u=full_u)
     dist.barrier()
     dist.destroy_process_group()
 

@@ -84,6 +84,7 @@ def test_sum_sync_equals_single_process_when_replicas_touch_disjoint_rows(tmp_pa
         ref.epoch = ref.epoch + 1
     np.testing.assert_allclose(ranks[0]["iw"], i1, rtol=0, atol=1e-5)      # (W - ref) + ref costs 1 ulp per sync, carried through training
     got_u = np.concatenate([ranks[0]["uw"], ranks[1]["uw"]])
+    assert np.array_equal(ranks[0]["full_u"], got_u) and np.array_equal(ranks[1]["full_u"], got_u)   # all_gather of the shards
     np.testing.assert_allclose(got_u, u1, rtol=0, atol=1e-5)               # user rows are private (never communicated)
 
 

@@ -446,3 +446,28 @@ def test_randomized_serial_parity_sweep():
         assert abs(lg - lo) <= 2e-5 * max(1.0, abs(lo)), ctx
         assert np.abs(ug - uo).max() <= 3e-4 * np.abs(uo).max(), ctx
         assert np.abs(ig - io).max() <= 3e-4 * np.abs(io).max(), ctx
+
+
+def test_distributed_main_under_torchrun(tmp_path):
+    """`torchrun -m heat_amd.cf.main --distributed`: the user-sharded trainer (device-mode engine on torch tensors, item
+    sync, loss and Recall reduced over ranks) end to end with one rank on this GPU (child process)."""
+    import os
+    import subprocess
+    import sys
+    import yaml
+    cfg = yaml.safe_load(open("heat_amd/cf/benchmarks/Gowalla/MF_CCL/configs/config_pr1.yaml"))
+    cfg["model_config"]["epochs"] = 3
+    cfg["model_config"]["eval_interval"] = 2
+    path = tmp_path / "cfg.yaml"
+    path.write_text(yaml.safe_dump(cfg))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+           "--master-port", "29581", "-m", "heat_amd.cf.main", "--config", str(path), "--synthetic", "gowalla", "--scale", "0.1",
+           "--distributed"]
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=280,
+                         env=dict(os.environ, MASTER_ADDR="127.0.0.1"))
+    out = res.stdout
+    assert res.returncode == 0, out[-3000:]
+    losses = [float(l.split("loss:")[1].split(";")[0]) for l in out.splitlines() if l.startswith("epoch:")]
+    assert len(losses) == 3 and losses[2] < losses[0]
+    rec = [float(l.split("Recall(k=20):")[1]) for l in out.splitlines() if l.startswith("[Metrics]")]
+    assert rec and 0.02 < rec[-1] < 1.0
