@@ -67,7 +67,6 @@ struct heat_cf_engine
     uint32_t* d_masks = nullptr;
     uint64_t  max_his = 0;
     bool     own_tables = false;
-    bool     pinned_user = false, pinned_item = false; // host buffers registered for DMA (host mode)
     uint64_t data_rows = 0;
     // scratch
     double*   d_loss_part = nullptr;
@@ -326,8 +325,6 @@ void destroy_impl(heat_cf_engine* e)
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     for (auto& q : e->ev_pending) { (void)hipEventDestroy(q.a); (void)hipEventDestroy(q.b); }
     for (auto& q : e->ev_free) { (void)hipEventDestroy(q.a); (void)hipEventDestroy(q.b); }
-    if (e->pinned_user) (void)hipHostUnregister(e->h_user_w);
-    if (e->pinned_item) (void)hipHostUnregister(e->h_item_w);
     if (e->own_tables)
     {
         (void)hipFree(e->d_user_w);
@@ -464,10 +461,6 @@ int heat_cf_engine_create(const heat_cf_config* cfg, const uint64_t* clicks, uin
         HIP_TRY(hipMalloc(&e->d_user_g, std::max<size_t>(user_bytes(e), 16)));
         HIP_TRY(hipMalloc(&e->d_item_g, std::max<size_t>(item_bytes(e), 16)));
         HIP_TRY(hipMalloc(&e->d_clicks, std::max<size_t>(data_rows * sizeof(uint2), 16)));
-        // page-lock the caller's weight buffers (best effort): the per-epoch write-back then runs at DMA speed
-        e->pinned_user = user_bytes(e) && hipHostRegister(user_w, user_bytes(e), hipHostRegisterDefault) == hipSuccess;
-        e->pinned_item = item_bytes(e) && hipHostRegister(item_w, item_bytes(e), hipHostRegisterDefault) == hipSuccess;
-        (void)hipGetLastError();
         HIP_TRY(hipMemcpyAsync(e->d_user_w, user_w, user_bytes(e), hipMemcpyHostToDevice, e->stream));
         HIP_TRY(hipMemcpyAsync(e->d_item_w, item_w, item_bytes(e), hipMemcpyHostToDevice, e->stream));
         HIP_TRY(hipMemcpyAsync(e->d_clicks, packed.data(), data_rows * sizeof(uint2), hipMemcpyHostToDevice, e->stream));
