@@ -182,6 +182,9 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(graph, d, N)
+            ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 8)
+            if ncpu > 8:   # also at all the cores this process may use
+                out["cpu_baseline_all_cores"] = cpu_baseline(graph, d, N, threads=ncpu, epochs=4)
         print(json.dumps(out), flush=True)
     if dist.is_initialized():
         dist.barrier()

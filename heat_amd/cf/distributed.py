@@ -25,9 +25,24 @@ def shard_bounds(num_users, world_size, rank):
     return start, start + k + (1 if rank < r else 0)
 
 
-def shard_clicks(clicks, num_users, world_size, rank):
+def shard_bounds_balanced(user_indptr, world_size, rank):
+    """Contiguous user range of `rank` with ~equal INTERACTION counts instead of equal user counts (ranges by
+    user count are not ranges by work; a deliberate deviation from cf/main.py:51-57).  `user_indptr` is the CSR row
+    pointer of the interaction list ([num_users+1])."""
+    indptr = np.asarray(user_indptr, dtype=np.int64)
+    n_users, total = indptr.size - 1, int(indptr[-1])
+    cuts = [0]
+    for r in range(1, world_size):
+        target = total * r // world_size
+        u = int(np.searchsorted(indptr, target, side="left"))
+        cuts.append(min(max(u, cuts[-1]), n_users))
+    cuts.append(n_users)
+    return cuts[rank], cuts[rank + 1]
+
+
+def shard_clicks(clicks, num_users, world_size, rank, bounds=None):
     """Interactions of the rank's users with user ids re-based to the shard (cf/datasets.py:120-137)."""
-    lo, hi = shard_bounds(num_users, world_size, rank)
+    lo, hi = shard_bounds(num_users, world_size, rank) if bounds is None else bounds
     u = clicks[:, 0]
     if u.size > 1 and np.any(u[1:] < u[:-1]):
         raise ValueError("the interaction list must be grouped by ascending user id (LightGCN order) to be sharded by user range")
@@ -120,7 +135,8 @@ class ShardedTrainer:
     (the CPU tests plug the oracle in that way)."""
 
     def __init__(self, clicks, user_w, item_w, *, num_negs, rank=None, world_size=None, device=None, seed=2022,
-                 refresh_interval=8192, sync_interactions=0, mode="sum", engine_factory=None, **cfg_kwargs):
+                 refresh_interval=8192, sync_interactions=0, mode="sum", engine_factory=None, balance="users",
+                 **cfg_kwargs):
         import torch
         import torch.distributed as dist
         self.torch = torch
@@ -128,7 +144,15 @@ class ShardedTrainer:
         self.world = dist.get_world_size() if world_size is None else world_size
         num_users = user_w.shape[0]
         self.num_users_total = num_users
-        self.shard, self.lo, self.hi = shard_clicks(clicks, num_users, self.world, self.rank)
+        self.bounds = None
+        if balance == "interactions":      # equal work per rank instead of equal user counts
+            indptr = np.concatenate([[0], np.cumsum(np.bincount(clicks[:, 0].astype(np.int64), minlength=num_users))])
+            self.all_bounds = [shard_bounds_balanced(indptr, self.world, r) for r in range(self.world)]
+        elif balance == "users":
+            self.all_bounds = [shard_bounds(num_users, self.world, r) for r in range(self.world)]
+        else:
+            raise ValueError("balance must be 'users' or 'interactions'")
+        self.shard, self.lo, self.hi = shard_clicks(clicks, num_users, self.world, self.rank, bounds=self.all_bounds[self.rank])
         base = int(np.searchsorted(clicks[:, 0], self.lo, side="left"))      # global index of the shard's first interaction
         if engine_factory is None:
             from heat_amd import abi
@@ -176,7 +200,7 @@ class ShardedTrainer:
             return self.t_user.cpu().numpy()
         torch = self.torch
         d = self.t_user.shape[1]
-        rows = [b - a for a, b in (shard_bounds(self.num_users_total, self.world, r) for r in range(self.world))]
+        rows = [b - a for a, b in self.all_bounds]
         pad = max(rows)
         mine = torch.zeros((pad, d), dtype=self.t_user.dtype, device=self.t_user.device)
         mine[:self.t_user.shape[0]] = self.t_user

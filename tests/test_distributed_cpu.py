@@ -8,7 +8,7 @@ import sys
 import numpy as np
 import pytest
 
-from heat_amd.cf.distributed import shard_bounds, shard_clicks
+from heat_amd.cf.distributed import shard_bounds, shard_bounds_balanced, shard_clicks
 from oracle import cf_oracle as orc
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -21,6 +21,19 @@ def test_shard_bounds_partition_all_users():
         assert all(spans[i][1] == spans[i + 1][0] for i in range(p - 1))
         sizes = [b - a for a, b in spans]
         assert max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)   # main.py:51-57: first r ranks get +1
+
+
+def test_balanced_shards_equalise_interactions():
+    rng = np.random.default_rng(0)
+    deg = (rng.pareto(1.5, size=5000) * 20 + 1).astype(np.int64)          # heavy-tailed user degrees
+    indptr = np.concatenate([[0], np.cumsum(deg)])
+    for p in (2, 4, 8):
+        spans = [shard_bounds_balanced(indptr, p, r) for r in range(p)]
+        assert spans[0][0] == 0 and spans[-1][1] == 5000 and all(spans[i][1] == spans[i + 1][0] for i in range(p - 1))
+        work = np.array([indptr[b] - indptr[a] for a, b in spans], dtype=np.float64)
+        by_users = np.array([indptr[b] - indptr[a] for a, b in (shard_bounds(5000, p, r) for r in range(p))], dtype=np.float64)
+        assert work.max() / work.mean() <= by_users.max() / by_users.mean() + 1e-9
+        assert work.max() / work.mean() < 1.0 + deg.max() * p / indptr[-1] + 1e-9   # within one user's degree of perfect
 
 
 def test_shard_clicks_rebases_users():
