@@ -14,11 +14,15 @@
 //   * an embedding row is read by LPR = emb_dim/4 (rounded up to 8/16/32/64) consecutive lanes, 16 B per lane
 //     (one `buffer_load_dwordx4` fetches R = 64/LPR whole rows); row-wise dot products are 4 DPP adds inside
 //     the 16-lane DPP row (+ ds_bpermute steps for 128/256-wide rows);
-//   * the N negatives sit in NG = ceil(N/R) register groups; per-negative scalars (norms, cosines, softmax
+//   * the N negatives sit in NGW x NW = ceil(N/R) register groups; per-negative scalars (norms, cosines, softmax
 //     weights) are computed once per row group, the softmax runs across groups and rows with two cross-row
 //     shuffles;
-//   * stores are Hogwild (plain overwrites of W and G rows, no atomics), exactly the reference's semantics;
-//     with AUX = sc1 the row traffic is device-coherent across the 8 XCD L2s;
+//   * write-back is Hogwild: per kind of row either the reference's literal overwrite or float atomic adds
+//     (W += -lr*G, G += G_new - G_read), shaped as 256 contiguous bytes per wave instruction through a 1 KiB LDS
+//     transpose tile; default policy: positive row atomic, negative rows overwritten (DESIGN.md "Hogwild at GPU
+//     concurrency").  With AUX = sc1 all row traffic is device-coherent across the 8 XCD L2s;
+//   * large num_negs: NW waves per workgroup share one stream (negative slots split across waves, softmax and user
+//     gradient exchanged through LDS); behaviour aggregation (AGG) keeps W0 and the last 32 gradient pairs in LDS;
 //   * negatives come from Philox4x32-10 keyed by (seed, epoch) with the interaction index as counter: no host
 //     round trip, no sampler state in memory, schedule-independent.
 #include "ccl_device.hpp"
