@@ -27,6 +27,26 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
 
 
+def usable_cpus():
+    """CPUs this process may actually use: the affinity mask, further limited by the cgroup CPU quota (containers)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 8)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                quota = int(txt[0])
+                period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if quota > 0:
+                    n = min(n, max(1, quota // period))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
 def cpu_baseline(graph, d, n_negs, threads=8, epochs=6):
     """The CPU oracle (a port of the reference's OpenMP path; the reference itself cannot be built here: Eigen is
     absent) timed on this box's host cores over a bounded sample: `epochs` passes of the same graph (~10-15 s of CPU
@@ -182,7 +202,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(graph, d, N)
-            ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 8)
+            ncpu = usable_cpus()
             if ncpu > 8:   # also at all the cores this process may use
                 out["cpu_baseline_all_cores"] = cpu_baseline(graph, d, N, threads=ncpu, epochs=4)
         print(json.dumps(out), flush=True)
