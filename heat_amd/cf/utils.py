@@ -1,7 +1,2 @@
-"""Mirror of the reference's cf/utils.py:5-9."""
-import yaml
-
-
-def load_config(config_path):
-    with open(config_path, "r") as f:
-        return yaml.safe_load(f)
+"""Import-compatible alias (the reference keeps these names in cf/utils.py); implementation: heat_amd.cf.frontend."""
+from .frontend import load_config  # noqa: F401
