@@ -754,10 +754,11 @@ bool pick_variant(uint32_t emb_dim, uint32_t num_negs, bool single_wave, int* lp
     }
     int best_cap = 0, best_g = 0, best_w = 0;
     // smallest capacity that fits; among equals the fewest register groups per wave (= most waves per workgroup):
-    // measured at Yelp18 shape <32,8,4> 0.81 > <32,16,2> 0.78 > <32,32,1> 0.74 of HBM peak (profiles/r01_variant_sweep.txt)
+    // measured at Yelp18 shape <32,8,4> 0.81 > <32,16,2> 0.78 > <32,32,1> 0.74 of HBM peak (profiles/r01_variant_sweep.txt);
+    // splitting a small interaction (<= 4 groups) over two waves is slower (<16,2,2> 0.75 vs <16,4,1> 0.85)
 #define X(L, G, W)                                                                                   \
     if (L == lpr && (uint32_t)(G * R * W) >= num_negs && (!single_wave || W == 1) &&                   \
-        (best_cap == 0 || G * R * W < best_cap || (G * R * W == best_cap && G < best_g)))              \
+        (best_cap == 0 || G * R * W < best_cap || (G * R * W == best_cap && G < best_g && G >= 8)))    \
     {                                                                                                  \
         best_cap = G * R * W;                                                                          \
         best_g = G;                                                                                    \
