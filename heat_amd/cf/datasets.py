@@ -11,13 +11,37 @@ import numpy as np
 from .cpp_base import CPPBase
 
 
+def _parse_cached(file_path, separator, cache):
+    """Native parse of a LightGCN text file with a binary side-car cache (`<file>.heatcf.npz`, keyed by the source's size
+    and mtime): the second load of a large file is one np.load instead of a text parse."""
+    import os
+    from heat_amd import abi
+    side = file_path + ".heatcf.npz"
+    st = os.stat(file_path)
+    key = np.array([st.st_size, st.st_mtime_ns, ord(separator[:1] or " ")], dtype=np.int64)
+    if cache and os.path.exists(side):
+        try:
+            with np.load(side, allow_pickle=False) as z:      # our own file; nothing executable in it
+                if np.array_equal(z["key"], key):
+                    return z["clicks"], z["line_user"], z["line_start"]
+        except (OSError, KeyError, ValueError):
+            pass
+    clicks, line_user, line_start = abi.parse_lightgcn(file_path, separator)
+    if cache:
+        try:
+            np.savez(side, key=key, clicks=clicks, line_user=line_user, line_start=line_start)
+        except OSError:
+            pass                                              # read-only dataset directory: just skip the cache
+    return clicks, line_user, line_start
+
+
 class Dataset(CPPBase):
     def __init__(self):
         super().__init__()
 
 
 class ClickDataset(Dataset):
-    def __init__(self, file_path=None, separator=' ', config=None, seed=2022, user_items=None, is_train=None):
+    def __init__(self, file_path=None, separator=' ', config=None, seed=2022, user_items=None, is_train=None, cache=True):
         """file_path: LightGCN txt; or user_items: {user_id: [items]} (synthetic graphs)."""
         super().__init__()
         self.file_path = file_path if file_path is not None else "<memory>"
@@ -26,8 +50,7 @@ class ClickDataset(Dataset):
         rnd = random.Random(seed)
         if user_items is None:
             # native one-pass parser (heat_cf_parse_lightgcn) instead of the reference's per-line Python loop
-            from heat_amd import abi
-            clicks, line_user, line_start = abi.parse_lightgcn(file_path, separator)
+            clicks, line_user, line_start = _parse_cached(file_path, separator, cache)
             items_all = clicks[:, 1]
             for k, u in enumerate(line_user.tolist()):
                 self.user_items_dic[u] = items_all[line_start[k]:line_start[k + 1]].tolist()   # a repeated user id: last line wins (datasets.py:56)

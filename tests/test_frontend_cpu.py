@@ -250,3 +250,21 @@ def test_launch_plan_host_logic():
         abi.plan(emb_dim=64, num_negs=0, num_users=10, num_items=10, train_size=1)
     with pytest.raises(ValueError):
         abi.plan(emb_dim=64, num_negs=4, num_users=10, num_items=10, train_size=1, milestones=())
+
+
+def test_ingest_cache_roundtrip(tmp_path):
+    """The binary side-car written next to a LightGCN file reproduces the parse and is invalidated when the file changes."""
+    import shutil
+    from heat_amd.cf.cf_config import CFConfig
+    from heat_amd.cf.datasets import ClickDataset
+    src = os.path.join(ROOT, "tests", "golden", "tiny_lightgcn", "train.txt")
+    path = tmp_path / "train.txt"
+    shutil.copy(src, path)
+    with contextlib.redirect_stdout(io.StringIO()):
+        a = ClickDataset(str(path), config=CFConfig(emb_dim=64, num_negs=4, max_his=4, milestones=[10]), seed=1)
+        assert os.path.exists(str(path) + ".heatcf.npz")
+        b = ClickDataset(str(path), config=CFConfig(emb_dim=64, num_negs=4, max_his=4, milestones=[10]), seed=1)
+        assert np.array_equal(a.click_dataset, b.click_dataset) and a.user_items_dic == b.user_items_dic
+        path.write_text(path.read_text() + "4 1 2\n")            # the source changed: the cache must not be used
+        c = ClickDataset(str(path), config=CFConfig(emb_dim=64, num_negs=4, max_his=4, milestones=[10]), seed=1)
+    assert c.click_dataset.shape[0] == a.click_dataset.shape[0] + 2 and c.user_items_dic[4] == [1, 2]
