@@ -134,8 +134,8 @@ def test_lightgcn_parser(golden_dir):
     from heat_amd.cf.datasets import ClickDataset
     with contextlib.redirect_stdout(io.StringIO()):
         cfg = CFConfig(emb_dim=64, num_negs=4, max_his=4, milestones=[10])
-        tr = ClickDataset(os.path.join(golden_dir, "tiny_lightgcn", "train.txt"), config=cfg, seed=1)
-        te = ClickDataset(os.path.join(golden_dir, "tiny_lightgcn", "test.txt"), config=cfg, seed=1)
+        tr = ClickDataset(os.path.join(golden_dir, "tiny_lightgcn", "train.txt"), config=cfg, seed=1, cache=False)
+        te = ClickDataset(os.path.join(golden_dir, "tiny_lightgcn", "test.txt"), config=cfg, seed=1, cache=False)
     assert tr.click_dataset.dtype == np.uint64
     assert tr.click_dataset.tolist() == [[0, 3], [0, 4], [0, 7], [1, 0], [1, 1], [1, 2], [1, 3], [1, 5], [1, 6], [2, 9],
                                          [3, 2], [3, 8]]
