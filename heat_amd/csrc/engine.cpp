@@ -11,7 +11,9 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -693,13 +695,10 @@ int heat_cf_evaluate0(heat_cf_engine* e, float* sim)
     return HEAT_CF_OK;
 }
 
-int heat_cf_topk(heat_cf_engine* e, uint64_t u_begin, uint64_t u_end, uint32_t k, const uint64_t* mask_indptr,
-                 const uint32_t* mask_items, uint32_t* topk)
+// Materialised path: sim panel -> mask -> k rounds of arg-max.  Any k; also the cross-check for the fused path.
+static int topk_panels(heat_cf_engine* e, uint64_t u_begin, uint64_t u_end, uint32_t k, const uint64_t* mask_indptr,
+                       const uint32_t* mask_items, uint32_t* topk)
 {
-    if (!e || !topk) return fail(HEAT_CF_EINVAL, "engine / topk is NULL");
-    if (u_begin > u_end || u_end > e->cfg.num_users) return fail(HEAT_CF_EINVAL, "user range out of bounds");
-    if (k == 0 || k > e->cfg.num_items) return fail(HEAT_CF_EINVAL, "k must be in [1, num_items]");
-    if (mask_indptr && !mask_items) return fail(HEAT_CF_EINVAL, "mask_items is NULL");
     HIP_TRY(hipSetDevice(e->device));
     const uint64_t nu = u_end - u_begin;
     if (nu == 0) return HEAT_CF_OK;
@@ -760,6 +759,147 @@ int heat_cf_topk(heat_cf_engine* e, uint64_t u_begin, uint64_t u_end, uint32_t k
     if (rc) return rc;
     HIP_TRY(err);
     return HEAT_CF_OK;
+}
+
+
+// Fused path (topk_fused.hip): scores live in registers only.  Users go in panels of at most 2^20 so the partial lists
+// stay small; mask rows are used as they are when sorted ascending and sorted into a private copy otherwise.
+static int topk_fused(heat_cf_engine* e, uint64_t u_begin, uint64_t u_end, uint32_t k, const uint64_t* mask_indptr,
+                      const uint32_t* mask_items, uint32_t* topk)
+{
+    const uint64_t nu = u_end - u_begin, I = e->cfg.num_items, d = e->cfg.emb_dim;
+    const bool trace = getenv("HEAT_CF_TRACE") != nullptr; // stderr: where the host time of this call goes
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+        return std::chrono::duration<double, std::milli>(b - a).count();
+    };
+    const auto t_start = now();
+    const uint64_t panel = std::min<uint64_t>(nu, 1ull << 20);
+    const uint32_t slots = 3 * e->cu_count; // 3 workgroups of 52 KB LDS per CU
+    const uint64_t last = nu % panel ? nu % panel : panel;
+    const size_t part_elems = (size_t)k * std::max<uint64_t>(panel * topk_fused_splits((uint32_t)panel, (uint32_t)I, slots),
+                                                             last * topk_fused_splits((uint32_t)last, (uint32_t)I, slots));
+    float*    d_pv = nullptr;
+    uint32_t* d_pi = nullptr;
+    uint32_t* d_topk = nullptr;
+    uint64_t* d_indptr = nullptr;
+    uint32_t* d_items = nullptr;
+    uint32_t* d_raw = nullptr;
+    void*     d_temp = nullptr;
+    size_t items_cap = 0, temp_cap = 0;
+    std::vector<uint64_t> rel;
+    hipError_t err = hipMalloc(&d_pv, part_elems * sizeof(float));
+    if (err == hipSuccess) err = hipMalloc(&d_pi, part_elems * sizeof(uint32_t));
+    if (err == hipSuccess) err = hipMalloc(&d_topk, (size_t)panel * k * sizeof(uint32_t));
+    if (err == hipSuccess && mask_indptr) err = hipMalloc(&d_indptr, (panel + 1) * sizeof(uint64_t));
+    int rc = HEAT_CF_OK;
+    const auto t_alloc = now();
+    double ms_check = 0, ms_kernel = 0;
+    for (uint64_t p0 = 0; p0 < nu && err == hipSuccess && rc == HEAT_CF_OK; p0 += panel)
+    {
+        const uint64_t rows = std::min(panel, nu - p0);
+        const uint64_t ug = u_begin + p0;
+        uint64_t n_items = 0;
+        const auto t0 = now();
+        if (mask_indptr)
+        {
+            const uint64_t lo = mask_indptr[ug], hi = mask_indptr[ug + rows];
+            if (hi < lo) { rc = fail(HEAT_CF_EINVAL, "mask_indptr must be non-decreasing"); break; }
+            rel.resize(rows + 1);
+            bool ascending = true, in_range = true, monotone = true;
+            for (uint64_t u = 0; u < rows; ++u)
+            {
+                const uint64_t a = mask_indptr[ug + u], b = mask_indptr[ug + u + 1];
+                rel[u] = a - lo;
+                if (a < lo || b < a || b > hi) { monotone = false; break; }
+                uint32_t prev = 0;
+                for (const uint32_t *q = mask_items + a, *qe = mask_items + b; q < qe; ++q)
+                {
+                    const uint32_t v = *q;
+                    in_range &= v < I;
+                    ascending &= v >= prev;
+                    prev = v;
+                }
+            }
+            rel[rows] = hi - lo;
+            if (!monotone) { rc = fail(HEAT_CF_EINVAL, "mask_indptr must be non-decreasing"); break; }
+            if (!in_range) { rc = fail(HEAT_CF_EINVAL, "mask_items holds an id out of range"); break; }
+            n_items = hi - lo;
+            if (n_items > 0xFFFFFFFFull) { rc = fail(HEAT_CF_EUNSUP, "more than 2^32 mask items in one user panel"); break; }
+            if (n_items > items_cap)
+            {
+                (void)hipStreamSynchronize(e->stream);
+                (void)hipFree(d_items);
+                (void)hipFree(d_raw);
+                d_items = d_raw = nullptr;
+                items_cap = (size_t)n_items;
+                err = hipMalloc(&d_items, items_cap * sizeof(uint32_t));
+                if (err == hipSuccess) err = hipMalloc(&d_raw, items_cap * sizeof(uint32_t));
+            }
+            if (err == hipSuccess) err = hipMemcpyAsync(d_indptr, rel.data(), (rows + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, e->stream);
+            if (err == hipSuccess && n_items)
+                err = hipMemcpyAsync(ascending ? d_items : d_raw, mask_items + lo, n_items * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream);
+            if (err == hipSuccess && n_items && !ascending)
+            {
+                // rows in file order (cf/datasets.py:31-79): order them on the device, one segmented sort
+                uint32_t id_bits = 1;
+                while (id_bits < 32 && (1ull << id_bits) < I) ++id_bits;
+                size_t need = 0;
+                err = sort_mask_rows(d_raw, d_items, (uint32_t)n_items, (uint32_t)rows, d_indptr, id_bits, nullptr, &need, e->stream);
+                if (err == hipSuccess && need > temp_cap)
+                {
+                    (void)hipStreamSynchronize(e->stream);
+                    (void)hipFree(d_temp);
+                    d_temp = nullptr;
+                    temp_cap = need;
+                    err = hipMalloc(&d_temp, temp_cap);
+                }
+                if (err == hipSuccess)
+                    err = sort_mask_rows(d_raw, d_items, (uint32_t)n_items, (uint32_t)rows, d_indptr, id_bits, d_temp, &need, e->stream);
+            }
+        }
+        const uint32_t splits = topk_fused_splits((uint32_t)rows, (uint32_t)I, slots);
+        const auto t1 = now();
+        ms_check += ms(t0, t1);
+        if (err == hipSuccess)
+            err = launch_topk_fused(e->d_user_w + ug * d, e->d_item_w, (uint32_t)rows, (uint32_t)I, (uint32_t)d, k,
+                                    mask_indptr ? d_indptr : nullptr, d_items, splits, d_pv, d_pi, d_topk, e->stream);
+        if (err == hipSuccess)
+            err = hipMemcpyAsync(topk + p0 * k, d_topk, (size_t)rows * k * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream);
+        if (err == hipSuccess) err = hipStreamSynchronize(e->stream); // rel is reused by the next panel
+        ms_kernel += ms(t1, now());
+    }
+    (void)hipStreamSynchronize(e->stream);
+    (void)hipFree(d_pv);
+    (void)hipFree(d_pi);
+    (void)hipFree(d_topk);
+    (void)hipFree(d_indptr);
+    (void)hipFree(d_items);
+    (void)hipFree(d_raw);
+    (void)hipFree(d_temp);
+    if (trace)
+        fprintf(stderr, "[heat_cf] topk fused: alloc %.2f ms, mask check+upload %.2f ms, kernels+download %.2f ms, total %.2f ms\n",
+                ms(t_start, t_alloc), ms_check, ms_kernel, ms(t_start, now()));
+    if (rc) return rc;
+    HIP_TRY(err);
+    return HEAT_CF_OK;
+}
+
+int heat_cf_topk(heat_cf_engine* e, uint64_t u_begin, uint64_t u_end, uint32_t k, const uint64_t* mask_indptr,
+                 const uint32_t* mask_items, uint32_t* topk)
+{
+    if (!e || !topk) return fail(HEAT_CF_EINVAL, "engine / topk is NULL");
+    if (u_begin > u_end || u_end > e->cfg.num_users) return fail(HEAT_CF_EINVAL, "user range out of bounds");
+    if (k == 0 || k > e->cfg.num_items) return fail(HEAT_CF_EINVAL, "k must be in [1, num_items]");
+    if (mask_indptr && !mask_items) return fail(HEAT_CF_EINVAL, "mask_items is NULL");
+    HIP_TRY(hipSetDevice(e->device));
+    if (u_end == u_begin) return HEAT_CF_OK;
+    // HEAT_CF_TOPK_PATH=panel forces the materialised path (tests compare the two)
+    const char* path = getenv("HEAT_CF_TOPK_PATH");
+    const bool want_panel = path && strcmp(path, "panel") == 0;
+    const bool can_fuse = k <= TOPK_FUSED_MAX_K && (e->cfg.emb_dim % 4) == 0 && e->cfg.num_items < 0xFFFFFF00ull;
+    if (can_fuse && !want_panel) return topk_fused(e, u_begin, u_end, k, mask_indptr, mask_items, topk);
+    return topk_panels(e, u_begin, u_end, k, mask_indptr, mask_items, topk);
 }
 
 int heat_cf_sync_to_host(heat_cf_engine* e)

@@ -292,6 +292,65 @@ def test_evaluate0_and_topk():
     eng.close()
 
 
+def _topk_want(sim, indptr, items, k):
+    masked = sim.copy()
+    if indptr is not None:
+        for u in range(sim.shape[0]):
+            masked[u, items[int(indptr[u]):int(indptr[u + 1])]] = -np.inf
+    return np.argsort(-masked, axis=1, kind="stable")[:, :k].astype(np.uint32)
+
+
+@pytest.mark.parametrize("U,I,d,k,case", [
+    (70, 333, 64, 20, "random"),        # one item split, ragged last tile, unsorted mask rows
+    (100, 5000, 64, 64, "random"),      # many item splits, k at the list capacity
+    (100, 5000, 128, 1, "random"),
+    (65, 700, 20, 7, "random"),         # emb_dim not a multiple of the 16-wide k slab
+    (3, 30, 4, 20, "mostly_masked"),    # fewer than k unmasked items: -inf entries fill the list in id order
+    (130, 3000, 64, 20, "ascending"),   # every tile beats the thresholds: queue overflow rounds on every tile
+    (64, 900, 64, 20, "ties"),          # repeated item rows: equal scores rank by item id
+    (1, 129, 8, 5, "random"),
+])
+def test_topk_fused_matches_numpy_and_panel_path(U, I, d, k, case, monkeypatch):
+    """the fused U*V^T + mask + top-k (no score matrix) returns exactly the ids numpy's stable
+    argsort picks from the oracle's dense scores (cf/metrics.py:21-29 semantics), and exactly what the materialised
+    panel path returns."""
+    rng = np.random.default_rng(U * 1000 + I)
+    uw, iw = synthetic.init_embeddings(U, I, d, seed=7)
+    if case == "ascending":
+        base = np.abs(uw[0]).astype(np.float32) + 0.01
+        uw[:] = base * rng.uniform(0.5, 2.0, size=(U, 1)).astype(np.float32)
+        iw[:] = base * (1.0 + np.arange(I, dtype=np.float32)[:, None] / I)
+    if case == "ties":
+        iw[1::2] = iw[0::2][: len(iw[1::2])]
+    clicks = np.array([[0, 1]], dtype=np.uint64)
+    lens = rng.integers(0, 12, size=U) if case != "mostly_masked" else np.full(U, I - 5)
+    indptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    items = np.concatenate([rng.choice(I, size=n, replace=False) for n in lens] + [np.zeros(0, np.int64)]).astype(np.uint32)
+    ref = orc.Engine(clicks, uw.copy(), iw.copy(), num_negs=1).evaluate0()
+    eng = abi.Engine(clicks, uw, iw, num_negs=1)
+    got = eng.topk(k, mask_indptr=indptr, mask_items=items)
+    assert np.array_equal(got, _topk_want(ref, indptr, items, k))
+    nomask = eng.topk(k)
+    assert np.array_equal(nomask, _topk_want(ref, None, None, k))
+    sub = eng.topk(k, mask_indptr=indptr, mask_items=items, u_begin=U // 2, u_end=U)
+    assert np.array_equal(sub, got[U // 2:])
+    monkeypatch.setenv("HEAT_CF_TOPK_PATH", "panel")
+    assert np.array_equal(eng.topk(k, mask_indptr=indptr, mask_items=items), got)
+    eng.close()
+
+
+def test_topk_fused_large_equals_panel_path(monkeypatch):
+    """At a size the dense numpy check is too slow for, the fused path must agree id for id with the panel path."""
+    g, d, N = synthetic.make_named("gowalla", scale=0.25)
+    uw, iw = synthetic.init_embeddings(g.num_users, g.num_items, d, seed=3)
+    eng = abi.Engine(g.clicks[:1].copy(), uw, iw, num_negs=N)
+    fused = eng.topk(50, mask_indptr=g.train_indptr, mask_items=g.train_items)
+    monkeypatch.setenv("HEAT_CF_TOPK_PATH", "panel")
+    panel = eng.topk(50, mask_indptr=g.train_indptr, mask_items=g.train_items)
+    assert np.array_equal(fused, panel)
+    eng.close()
+
+
 def test_bad_arguments_raise():
     uw, iw = synthetic.init_embeddings(4, 8, 64)
     with pytest.raises(ValueError):
