@@ -169,9 +169,11 @@ class Engine:
 
     @classmethod
     def from_device(cls, clicks_ptr, data_rows, user_w_ptr, item_w_ptr, *, num_users, num_items, emb_dim, num_negs,
-                    stream=None, keep=None, **cfg_kwargs):
+                    stream=None, keep=None, his_ptr=None, max_his=0, masks_ptr=None, w0_ptr=None, **cfg_kwargs):
         """Device pointers (ints): clicks [data_rows,2] u64, user_w [num_users,emb_dim] f32, item_w [num_items,emb_dim]
-        f32, all owned by the caller; `stream` is a hipStream_t handle (int) or None; `keep` holds references alive."""
+        f32, all owned by the caller; `stream` is a hipStream_t handle (int) or None; `keep` holds references alive.
+        With use_aggregator=1: his [num_users,max_his] u64, masks [num_users] u64, w0 [emb_dim,emb_dim] f32 (trained
+        in place) are device pointers too."""
         self = cls.__new__(cls)
         self._keep = keep
         self.num_negs = num_negs
@@ -179,8 +181,11 @@ class Engine:
         self.cfg = make_config(emb_dim=emb_dim, num_negs=num_negs, num_users=num_users, num_items=num_items,
                                train_size=data_rows, **cfg_kwargs)
         self._h = C.c_void_p()
-        _check(load().heat_cf_engine_create_device(C.byref(self.cfg), C.c_void_p(clicks_ptr), data_rows, None, 0, None,
-                                                   C.c_void_p(user_w_ptr), C.c_void_p(item_w_ptr), None,
+        _check(load().heat_cf_engine_create_device(C.byref(self.cfg), C.c_void_p(clicks_ptr), data_rows,
+                                                   C.c_void_p(his_ptr) if his_ptr else None, max_his,
+                                                   C.c_void_p(masks_ptr) if masks_ptr else None,
+                                                   C.c_void_p(user_w_ptr), C.c_void_p(item_w_ptr),
+                                                   C.c_void_p(w0_ptr) if w0_ptr else None,
                                                    C.c_void_p(stream) if stream else None, C.byref(self._h)))
         return self
 

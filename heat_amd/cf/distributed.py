@@ -10,7 +10,8 @@ Synchronisation rule.  Between two syncs every rank trains a window of its own s
                                                             analogue of the in-GPU scatter-add; default)
     W_item <- mean_r W_item,r                              (mode "mean": the fork's intent, engine.cpp:366-375)
 where W_ref is the table right after the previous sync.  The persistent gradient rows G stay local (the reference
-never communicates them).  Window length: `sync_interactions` per rank; by default streams x refresh_interval
+never communicates them).  With behaviour aggregation on, the d x d aggregator matrix W0 is replicated and averaged
+over ranks at the same points (engine.cpp:355-359: MPI_Allreduce SUM, then / world_size).  Window length: `sync_interactions` per rank; by default streams x refresh_interval
 (refresh_interval is a per-worker step count in the reference — negative_samplers/random_tile_negative_sampler.cpp:33 —
 and a worker here is one wave-stream), capped at one epoch.
 """
@@ -57,14 +58,14 @@ class ItemSync:
     data_rows) through epochs cut into windows, all-reducing `item_w` (a torch tensor aliasing the engine's table)."""
 
     def __init__(self, engine, item_w, world_size, refresh_interval=8192, sync_interactions=0, mode="sum", streams=0,
-                 force_collective=False):
+                 force_collective=False, mean_tensors=()):
         import torch.distributed as dist
         self.dist = dist
         self.engine = engine
         self.item_w = item_w
         self.world = world_size
         self.mode = mode
-        n = engine.data_rows
+        self.mean_tensors = tuple(mean_tensors)   # replicated small state averaged at every sync (aggregator W0)
         if sync_interactions <= 0:
             streams = streams or getattr(engine, "num_streams", 0) or 3022
             sync_interactions = streams * refresh_interval
@@ -77,12 +78,15 @@ class ItemSync:
             raise ValueError("mode must be 'sum' or 'mean'")
 
     def describe(self):
-        return {"collective": "all_reduce(item table)", "mode": self.mode,
+        return {"collective": "all_reduce(item table)" + (" + all_reduce(W0)" if self.mean_tensors else ""), "mode": self.mode,
                 "window_interactions_per_gpu": min(self.window, self.engine.data_rows)}
 
     def sync(self):
         if self.world == 1 and not self.force:
             return
+        for t in self.mean_tensors:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+            t.div_(self.world)
         if self.mode == "mean":
             self.dist.all_reduce(self.item_w, op=self.dist.ReduceOp.SUM)
             self.item_w.div_(self.world)
@@ -131,12 +135,16 @@ class ShardedTrainer:
         for epoch in range(E): trainer.train_one_epoch()
         user_w_shard, item_w = trainer.weights()           # numpy; users [lo, hi) of this rank
 
+    Behaviour aggregation (ACCL): pass `his` [num_users, max_his] u64, `masks` [num_users] u64 and `w0` [d, d] f32; the
+    history rows follow their users into the shard, W0 is replicated and averaged at every sync.
+
     `engine_factory(shard_clicks, user_w_shard_tensor, item_w_tensor, sample_index_base)` may replace the HIP engine
-    (the CPU tests plug the oracle in that way)."""
+    (the CPU tests plug the oracle in that way); with aggregation it is also handed `his=, masks=, w0=` (shard rows,
+    shard lengths, the W0 tensor)."""
 
     def __init__(self, clicks, user_w, item_w, *, num_negs, rank=None, world_size=None, device=None, seed=2022,
                  refresh_interval=8192, sync_interactions=0, mode="sum", engine_factory=None, balance="users",
-                 **cfg_kwargs):
+                 his=None, masks=None, w0=None, **cfg_kwargs):
         import torch
         import torch.distributed as dist
         self.torch = torch
@@ -154,6 +162,13 @@ class ShardedTrainer:
             raise ValueError("balance must be 'users' or 'interactions'")
         self.shard, self.lo, self.hi = shard_clicks(clicks, num_users, self.world, self.rank, bounds=self.all_bounds[self.rank])
         base = int(np.searchsorted(clicks[:, 0], self.lo, side="left"))      # global index of the shard's first interaction
+        self.aggregate = w0 is not None
+        if self.aggregate and (his is None or masks is None):
+            raise ValueError("behaviour aggregation needs his, masks and w0")
+        self.t_w0 = None
+        if self.aggregate:
+            his_shard = np.ascontiguousarray(np.asarray(his, dtype=np.uint64)[self.lo:self.hi])
+            masks_shard = np.ascontiguousarray(np.asarray(masks, dtype=np.uint64).reshape(-1)[self.lo:self.hi])
         if engine_factory is None:
             from heat_amd import abi
             dev = torch.device("cuda", torch.cuda.current_device()) if device is None else device
@@ -162,17 +177,32 @@ class ShardedTrainer:
             self.t_item = torch.from_numpy(np.ascontiguousarray(item_w)).to(dev)
             stream = torch.cuda.current_stream().cuda_stream
             flags = cfg_kwargs.pop("flags", 0) | (0 if stream else abi.FLAG_NULL_STREAM)
+            agg = {}
+            keep_agg = ()
+            if self.aggregate:
+                t_his = torch.from_numpy(his_shard.view(np.int64)).to(dev)
+                t_masks = torch.from_numpy(masks_shard.view(np.int64)).to(dev)
+                self.t_w0 = torch.from_numpy(np.ascontiguousarray(w0, dtype=np.float32)).to(dev)
+                agg = dict(his_ptr=t_his.data_ptr(), max_his=his_shard.shape[1], masks_ptr=t_masks.data_ptr(),
+                           w0_ptr=self.t_w0.data_ptr(), use_aggregator=1)
+                keep_agg = (t_his, t_masks, self.t_w0)
             self.engine = abi.Engine.from_device(
                 self.t_clicks.data_ptr(), self.shard.shape[0], self.t_user.data_ptr(), self.t_item.data_ptr(),
                 num_users=self.hi - self.lo, num_items=item_w.shape[0], emb_dim=item_w.shape[1], num_negs=num_negs,
                 stream=stream or None, seed=seed, sample_index_base=base, flags=flags, device=dev.index,
-                keep=(self.t_clicks, self.t_user, self.t_item), **cfg_kwargs)
+                keep=(self.t_clicks, self.t_user, self.t_item) + keep_agg, **agg, **cfg_kwargs)
         else:
             self.t_user = torch.from_numpy(np.ascontiguousarray(user_w[self.lo:self.hi]).copy())
             self.t_item = torch.from_numpy(np.ascontiguousarray(item_w).copy())
-            self.engine = engine_factory(self.shard, self.t_user, self.t_item, base)
+            if self.aggregate:
+                self.t_w0 = torch.from_numpy(np.ascontiguousarray(w0, dtype=np.float32).copy())
+                self.engine = engine_factory(self.shard, self.t_user, self.t_item, base, his=his_shard, masks=masks_shard,
+                                             w0=self.t_w0)
+            else:
+                self.engine = engine_factory(self.shard, self.t_user, self.t_item, base)
         self.sync = ItemSync(self.engine, self.t_item, self.world, refresh_interval=refresh_interval,
-                             sync_interactions=sync_interactions, mode=mode)
+                             sync_interactions=sync_interactions, mode=mode,
+                             mean_tensors=(self.t_w0,) if self.aggregate else ())
 
     def train_one_epoch(self, want_loss=False):
         """One epoch on this rank's shard.  want_loss=True returns the GLOBAL mean loss (loss sums and interaction counts
@@ -192,6 +222,14 @@ class ShardedTrainer:
         if self.t_item.is_cuda:
             self.torch.cuda.current_stream().synchronize()
         return self.t_user.cpu().numpy(), self.t_item.cpu().numpy()
+
+    def aggregator_weights(self):
+        """The replicated W0 [d, d] (None without behaviour aggregation)."""
+        if self.t_w0 is None:
+            return None
+        if self.t_w0.is_cuda:
+            self.torch.cuda.current_stream().synchronize()
+        return self.t_w0.cpu().numpy()
 
     def gather_user_weights(self):
         """The full user table on every rank (all_gather of the shards; shards differ by at most one row)."""

@@ -38,13 +38,18 @@ def _main_distributed(args, model_config, cf_config, train_data, test_data, seed
     torch.cuda.set_device(local_rank)
     dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     rank, world = dist.get_rank(), dist.get_world_size()
+    agg = {}
+    if getattr(cf_config, "use_aggregator", False):             # ACCL: history rows follow their users, W0 is replicated
+        cf_config.init_c_instance()
+        w0 = AggregatorWeights(cf_config).aggregator_weights0   # drawn before the tables, as in the one-GPU flow below
+        agg = dict(his=train_data.his_items, masks=train_data.masks, w0=w0)
     model = MatrixFactorization(cf_config)                      # identical initial tables on every rank (same torch seed)
     user_w = model.user_embedding.weight.detach().cpu().numpy()
     item_w = model.item_embedding.weight.detach().cpu().numpy()
     trainer = ShardedTrainer(train_data.click_dataset, user_w, item_w, num_negs=cf_config.num_negs, seed=seed,
                              clip_val=cf_config.clip_val, l_r=cf_config.l_r, milestones=tuple(cf_config.milestones),
                              refresh_interval=cf_config.refresh_interval, neg_sampler=cf_config.neg_sampler,
-                             tile_size=cf_config.tile_size)
+                             tile_size=cf_config.tile_size, **agg)
     lo, hi = trainer.lo, trainer.hi
     indptr, items = train_data.train_csr()
     local_indptr = (indptr[lo:hi + 1] - indptr[lo]).astype(np.uint64)

@@ -655,6 +655,34 @@ __global__ void pack_clicks_kernel(const uint64_t* in, uint2* out, uint64_t n, u
     atomicMax(max_item, (uint32_t)it);
 }
 
+// Device-mode twin of the host loop in heat_cf_engine_create: history ids and lengths to u32, slots past the length
+// zeroed, bad[0] |= 1 for a length above max_his, |= 2 for an id outside the item table.
+__global__ void pack_history_kernel(const uint64_t* his, const uint64_t* masks, uint32_t* his32, uint32_t* masks32,
+                                    uint64_t num_users, uint32_t max_his, uint64_t num_items, uint32_t* bad)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= num_users * max_his) return;
+    const uint64_t u = t / max_his, k = t % max_his;
+    const uint64_t h = masks[u];
+    if (k == 0)
+    {
+        masks32[u] = (uint32_t)(h > max_his ? max_his : h);
+        if (h > max_his) atomicOr(bad, 1u);
+    }
+    const uint64_t it = his[t];
+    if (k < h && it >= num_items) atomicOr(bad, 2u);
+    his32[t] = (k < h && it < num_items) ? (uint32_t)it : 0u;
+}
+
+// behavior_aggregators.cpp:63 divides by masks[u]: bad[0] |= 4 when a user with interactions has an empty history
+__global__ void check_history_kernel(const uint2* clicks, uint64_t n, const uint32_t* masks32, uint64_t num_users, uint32_t* bad)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t u = clicks[i].x;
+    if (u < num_users && masks32[u] == 0) atomicOr(bad, 4u);
+}
+
 // Sampler-only kernel: the ids the training kernel draws for interactions [begin,end) (tests, oracle feeding).
 // One wave walks the range sequentially so that the ignore_pos "slot keeps previous id" state is reproduced for the
 // stream layout given by per_block.
@@ -823,6 +851,20 @@ hipError_t launch_pack_clicks(const uint64_t* in, uint2* out, uint64_t n, uint32
     if (n == 0) return hipSuccess;
     const uint32_t blocks = (uint32_t)((n + 255) / 256);
     hipLaunchKernelGGL(pack_clicks_kernel, dim3(blocks), dim3(256), 0, s, in, out, n, stats, stats + 1, stats + 2);
+    return hipGetLastError();
+}
+
+hipError_t launch_pack_history(const uint64_t* his, const uint64_t* masks, uint32_t* his32, uint32_t* masks32,
+                               uint64_t num_users, uint32_t max_his, uint64_t num_items, const uint2* clicks,
+                               uint64_t data_rows, uint32_t* bad, hipStream_t s)
+{
+    const uint64_t n = num_users * max_his;
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(pack_history_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, his, masks, his32, masks32,
+                       num_users, max_his, num_items, bad);
+    if (data_rows)
+        hipLaunchKernelGGL(check_history_kernel, dim3((uint32_t)((data_rows + 255) / 256)), dim3(256), 0, s, clicks, data_rows,
+                           masks32, num_users, bad);
     return hipGetLastError();
 }
 

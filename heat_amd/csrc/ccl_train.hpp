@@ -49,6 +49,9 @@ hipError_t launch_train(const TrainArgs& a, int lpr, int ng, int nw, uint32_t gr
 int        query_blocks_per_cu(int lpr, int ng, int nw, int aux, bool agg, uint32_t emb_dim);
 hipError_t launch_loss_reduce(const double* part, uint32_t n, double* out, hipStream_t s);
 hipError_t launch_pack_clicks(const uint64_t* in, uint2* out, uint64_t n, uint32_t* stats, hipStream_t s);
+hipError_t launch_pack_history(const uint64_t* his, const uint64_t* masks, uint32_t* his32, uint32_t* masks32,
+                               uint64_t num_users, uint32_t max_his, uint64_t num_items, const uint2* clicks,
+                               uint64_t data_rows, uint32_t* bad, hipStream_t s);
 hipError_t launch_sample_negs(const TrainArgs& a, uint32_t grid, uint64_t out_base, uint64_t* out, hipStream_t s);
 
 } // namespace heatcf

@@ -385,6 +385,15 @@ int heat_cf_device_count(void)
     return n;
 }
 
+static int aggregator_limits(const heat_cf_config* cfg, uint64_t max_his, int lpr, int nw)
+{
+    if (nw != 1) return fail(HEAT_CF_EUNSUP, "behaviour aggregation is built for single-wave variants (num_negs <= 64 rows per wave)");
+    if (max_his == 0 || max_his > 128) return fail(HEAT_CF_EUNSUP, "behaviour aggregation supports 1 <= max_his <= 128");
+    if ((cfg->emb_dim * cfg->emb_dim + 32 * 2 * 4 * (uint64_t)lpr + 4 * (uint64_t)lpr) * 4 > 160 * 1024)
+        return fail(HEAT_CF_EUNSUP, "behaviour aggregation keeps W0 in LDS: emb_dim too large");
+    return HEAT_CF_OK;
+}
+
 int heat_cf_engine_create(const heat_cf_config* cfg, const uint64_t* clicks, uint64_t data_rows, const uint64_t* his,
                           uint64_t max_his, const uint64_t* masks, float* user_w, float* item_w, float* w0,
                           heat_cf_engine** out)
@@ -399,10 +408,8 @@ int heat_cf_engine_create(const heat_cf_config* cfg, const uint64_t* clicks, uin
     if (cfg->use_aggregator)
     {
         if (!his || !masks || !w0) return fail(HEAT_CF_EINVAL, "use_aggregator needs historical_items, masks and aggregator weights");
-        if (nw != 1) return fail(HEAT_CF_EUNSUP, "behaviour aggregation is built for single-wave variants (num_negs <= 64 rows per wave)");
-        if (max_his == 0 || max_his > 128) return fail(HEAT_CF_EUNSUP, "behaviour aggregation supports 1 <= max_his <= 128");
-        if ((cfg->emb_dim * cfg->emb_dim + 32 * 2 * 4 * (uint64_t)lpr + 4 * (uint64_t)lpr) * 4 > 160 * 1024)
-            return fail(HEAT_CF_EUNSUP, "behaviour aggregation keeps W0 in LDS: emb_dim too large");
+        rc = aggregator_limits(cfg, max_his, lpr, nw);
+        if (rc) return rc;
         try { his32.resize(cfg->num_users * max_his); masks32.resize(cfg->num_users); }
         catch (const std::bad_alloc&) { return fail(HEAT_CF_ENOMEM, "host allocation failed"); }
         for (uint64_t u = 0; u < cfg->num_users; ++u)
@@ -492,7 +499,6 @@ int heat_cf_engine_create_device(const heat_cf_config* cfg, const void* d_clicks
                                  uint64_t max_his, const void* d_masks, void* d_user_w, void* d_item_w, void* d_w0,
                                  void* stream, heat_cf_engine** out)
 {
-    (void)d_his; (void)max_his; (void)d_masks;
     if (!out) return fail(HEAT_CF_EINVAL, "out is NULL");
     *out = nullptr;
     int lpr = 0, ng = 0, nw = 1;
@@ -500,7 +506,13 @@ int heat_cf_engine_create_device(const heat_cf_config* cfg, const void* d_clicks
     if (rc) return rc;
     if (!d_clicks && data_rows) return fail(HEAT_CF_EINVAL, "d_clicks is NULL");
     if (!d_user_w || !d_item_w) return fail(HEAT_CF_EINVAL, "d_user_w / d_item_w is NULL");
-    if (cfg->use_aggregator) return fail(HEAT_CF_EUNSUP, "behaviour aggregation is available in host mode only");
+    if (cfg->use_aggregator)
+    {
+        if (!d_his || !d_masks || !d_w0) return fail(HEAT_CF_EINVAL, "use_aggregator needs historical_items, masks and aggregator weights");
+        rc = aggregator_limits(cfg, max_his, lpr, nw);
+        if (rc) return rc;
+        if ((uintptr_t)d_w0 & 15u) return fail(HEAT_CF_EINVAL, "aggregator weights must be 16-byte aligned");
+    }
     if (((uintptr_t)d_user_w | (uintptr_t)d_item_w) & 15u) return fail(HEAT_CF_EINVAL, "tables must be 16-byte aligned");
     heat_cf_engine* e = new (std::nothrow) heat_cf_engine();
     if (!e) return fail(HEAT_CF_ENOMEM, "host allocation failed");
@@ -521,11 +533,22 @@ int heat_cf_engine_create_device(const heat_cf_config* cfg, const void* d_clicks
         HIP_TRY(hipMemsetAsync(e->d_item_g, 0, item_bytes(e), e->stream));
         HIP_TRY(hipMemsetAsync(e->d_stats, 0, 4 * sizeof(uint32_t), e->stream));
         HIP_TRY(launch_pack_clicks((const uint64_t*)d_clicks, e->d_clicks, data_rows, e->d_stats, e->stream));
+        if (cfg->use_aggregator)
+        {
+            e->max_his = max_his;
+            HIP_TRY(hipMalloc(&e->d_his, std::max<size_t>(cfg->num_users * max_his * sizeof(uint32_t), 16)));
+            HIP_TRY(hipMalloc(&e->d_masks, std::max<size_t>(cfg->num_users * sizeof(uint32_t), 16)));
+            HIP_TRY(launch_pack_history((const uint64_t*)d_his, (const uint64_t*)d_masks, e->d_his, e->d_masks, cfg->num_users,
+                                        (uint32_t)max_his, cfg->num_items, e->d_clicks, data_rows, e->d_stats + 3, e->stream));
+        }
         uint32_t stats[4] = {0, 0, 0, 0};
         HIP_TRY(hipMemcpyAsync(stats, e->d_stats, sizeof(stats), hipMemcpyDeviceToHost, e->stream));
         HIP_TRY(hipStreamSynchronize(e->stream));
         if (data_rows && (stats[2] || stats[0] >= cfg->num_users || stats[1] >= cfg->num_items))
             return fail(HEAT_CF_EINVAL, "click_dataset holds an id out of range");
+        if (stats[3] & 1u) return fail(HEAT_CF_EINVAL, "masks holds a length above max_his");
+        if (stats[3] & 2u) return fail(HEAT_CF_EINVAL, "historical_items holds an id out of range");
+        if (stats[3] & 4u) return fail(HEAT_CF_EINVAL, "a user has interactions but masks == 0");
         return HEAT_CF_OK;
     };
     CREATE_TRY(body());

@@ -17,8 +17,8 @@ from oracle import cf_oracle as orc  # noqa: E402
 class OracleWindows:
     """begin_epoch / train_range / end_epoch on top of the oracle, with caller-fed negatives."""
 
-    def __init__(self, clicks, uw, iw, negs, num_negs, lr):
-        self.e = orc.Engine(clicks, uw, iw, num_negs=num_negs, l_r=lr, clip_val=1.0)
+    def __init__(self, clicks, uw, iw, negs, num_negs, lr, **agg):
+        self.e = orc.Engine(clicks, uw, iw, num_negs=num_negs, l_r=lr, clip_val=1.0, **agg)
         self.negs = negs
         self.data_rows = clicks.shape[0]
 
@@ -41,17 +41,21 @@ def main():
     clicks, num_users = data["clicks"], int(data["num_users"])
     all_negs, N, lr = data["negs"], int(data["num_negs"]), float(data["lr"])
 
-    def oracle_factory(shard, t_user, t_item, base):
+    def oracle_factory(shard, t_user, t_item, base, his=None, masks=None, w0=None):
         # the tensors share memory with the numpy views the oracle borrows and trains in place
-        return OracleWindows(shard, t_user.numpy(), t_item.numpy(), all_negs[base:base + shard.shape[0]], N, lr)
+        agg = {} if w0 is None else dict(his=his, masks=masks, w0=w0.numpy(), use_aggregator=True)
+        return OracleWindows(shard, t_user.numpy(), t_item.numpy(), all_negs[base:base + shard.shape[0]], N, lr, **agg)
 
+    agg = dict(his=data["his"], masks=data["masks"], w0=data["w0"]) if "w0" in data.files else {}
     tr = ShardedTrainer(clicks, data["uw"], data["iw"], num_negs=N, sync_interactions=window, mode=mode,
-                        engine_factory=oracle_factory)
+                        engine_factory=oracle_factory, **agg)
     for _ in range(int(data["epochs"])):
         tr.train_one_epoch()
     uw, iw = tr.weights()
     full_u = tr.gather_user_weights()
-    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), uw=uw, iw=iw, lo=tr.lo, hi=tr.hi, rows=tr.shard.shape[0], full_u=full_u)
+    extra = {} if tr.aggregator_weights() is None else {"w0": tr.aggregator_weights()}
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), uw=uw, iw=iw, lo=tr.lo, hi=tr.hi, rows=tr.shard.shape[0], full_u=full_u,
+             **extra)
     dist.barrier()
     dist.destroy_process_group()
 

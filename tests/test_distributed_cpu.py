@@ -136,3 +136,33 @@ def test_sum_sync_overlapping_rows_applies_both_deltas(tmp_path):
         reps.append(i)
     want = iw + (reps[0] - iw) + (reps[1] - iw)
     np.testing.assert_allclose(ranks[0]["iw"], want, rtol=0, atol=3e-7)
+
+
+@pytest.mark.timeout(400)
+def test_aggregator_weights_are_averaged_with_the_item_table(tmp_path):
+    """with behaviour aggregation on, W0 is all-reduce-averaged at the same points as the item table
+    (train/engine.cpp:355-359, 366-375)."""
+    clicks, negs, uw, iw, U, N = make_problem(tmp_path, disjoint_items=False, epochs=1)
+    rng = np.random.default_rng(5)
+    d, I, max_his = uw.shape[1], iw.shape[0], 6
+    masks = rng.integers(1, max_his + 1, U).astype(np.uint64)
+    his = rng.integers(0, I, (U, max_his)).astype(np.uint64)
+    w0 = (rng.standard_normal((d, d)) * 0.1).astype(np.float32)
+    prob = dict(np.load(tmp_path / "problem.npz"))
+    np.savez(tmp_path / "problem.npz", his=his, masks=masks, w0=w0, **prob)
+    ranks = run_world(tmp_path, "mean", window=10 ** 9)                    # one sync, at the end of the epoch
+    assert np.array_equal(ranks[0]["iw"], ranks[1]["iw"]) and np.array_equal(ranks[0]["w0"], ranks[1]["w0"])
+    reps_i, reps_w = [], []
+    for r in range(2):
+        shard, lo, hi = shard_clicks(clicks, U, 2, r)
+        a = int(np.searchsorted(clicks[:, 0], lo))
+        u, i, w = uw[lo:hi].copy(), iw.copy(), w0.copy()
+        e = orc.Engine(shard, u, i, num_negs=N, l_r=0.01, clip_val=1.0, his=np.ascontiguousarray(his[lo:hi]),
+                       masks=np.ascontiguousarray(masks[lo:hi]), w0=w, use_aggregator=True)
+        e.lr_step()
+        e.train_range(0, shard.shape[0], negs[a:a + shard.shape[0]])
+        reps_i.append(i)
+        reps_w.append(w)
+    assert not np.array_equal(reps_w[0], w0)                               # W0 did move
+    np.testing.assert_allclose(ranks[0]["iw"], (reps_i[0] + reps_i[1]) / 2, rtol=0, atol=1e-7)
+    np.testing.assert_allclose(ranks[0]["w0"], (reps_w[0] + reps_w[1]) / 2, rtol=0, atol=1e-7)

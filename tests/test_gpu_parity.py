@@ -128,6 +128,54 @@ def test_aggregator_serial_walk_matches_oracle(d, N, H):
     assert_tables_close(ig, io, scale=np.abs(io).max(), rtol=5e-4)
 
 
+def test_aggregator_device_mode_equals_host_mode():
+    """Device-resident ACCL (heat_cf_engine_create_device with history, lengths and W0 as device pointers, the form the
+    sharded trainer uses) runs the same kernels as the host-mode engine: identical tables and W0 after two epochs."""
+    import torch
+    d, N, H, U, I, T = 64, 8, 20, 30, 500, 900
+    rng = np.random.default_rng(11)
+    clicks = np.stack([np.sort(rng.integers(0, U, T)), rng.integers(0, I, T)], axis=1).astype(np.uint64)
+    uw = (rng.standard_normal((U, d)) * 0.1).astype(np.float32)
+    iw = (rng.standard_normal((I, d)) * 0.1).astype(np.float32)
+    w0 = (rng.standard_normal((d, d)) * 0.1).astype(np.float32)
+    his = rng.integers(0, I, size=(U, H)).astype(np.uint64)
+    masks = rng.integers(1, H + 1, size=(U, 1)).astype(np.uint64)
+    uh, ih, wh = uw.copy(), iw.copy(), w0.copy()
+    host = abi.Engine(clicks, uh, ih, num_negs=N, his=his, masks=masks, w0=wh, use_aggregator=True, seed=4,
+                      flags=abi.FLAG_SERIAL)
+    losses_h = [host.train_one_epoch() for _ in range(2)]
+    host.close()
+    dev = torch.device("cuda", 0)
+    side = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(side):
+        t = {k: torch.from_numpy(v).to(dev) for k, v in dict(c=clicks.view(np.int64), u=uw, i=iw, w=w0, h=his.view(np.int64),
+                                                             m=masks.view(np.int64)).items()}
+        common = dict(num_users=U, num_items=I, emb_dim=d, num_negs=N, stream=side.cuda_stream, seed=4,
+                      flags=abi.FLAG_SERIAL, keep=tuple(t.values()), max_his=H, use_aggregator=1)
+        eng = abi.Engine.from_device(t["c"].data_ptr(), T, t["u"].data_ptr(), t["i"].data_ptr(), his_ptr=t["h"].data_ptr(),
+                                     masks_ptr=t["m"].data_ptr(), w0_ptr=t["w"].data_ptr(), **common)
+        losses_d = [eng.train_one_epoch() for _ in range(2)]
+        side.synchronize()
+        eng.close()
+        assert losses_d == losses_h
+        assert np.array_equal(t["u"].cpu().numpy(), uh) and np.array_equal(t["i"].cpu().numpy(), ih)
+        assert np.array_equal(t["w"].cpu().numpy(), wh) and not np.array_equal(wh, w0)
+        # the device-side checks mirror the host ones
+        bad_m = torch.full_like(t["m"], H + 1)
+        with pytest.raises(ValueError):
+            abi.Engine.from_device(t["c"].data_ptr(), T, t["u"].data_ptr(), t["i"].data_ptr(), his_ptr=t["h"].data_ptr(),
+                                   masks_ptr=bad_m.data_ptr(), w0_ptr=t["w"].data_ptr(), **common)
+        zero_m = torch.zeros_like(t["m"])
+        with pytest.raises(ValueError):
+            abi.Engine.from_device(t["c"].data_ptr(), T, t["u"].data_ptr(), t["i"].data_ptr(), his_ptr=t["h"].data_ptr(),
+                                   masks_ptr=zero_m.data_ptr(), w0_ptr=t["w"].data_ptr(), **common)
+        bad_h = torch.full_like(t["h"], I)
+        with pytest.raises(ValueError):
+            abi.Engine.from_device(t["c"].data_ptr(), T, t["u"].data_ptr(), t["i"].data_ptr(), his_ptr=bad_h.data_ptr(),
+                                   masks_ptr=t["m"].data_ptr(), w0_ptr=t["w"].data_ptr(), **common)
+        side.synchronize()
+
+
 def test_sampler_is_philox_bit_exact():
     d, N, U, I, T = 64, 16, 50, 1000, 2000
     clicks, uw, iw = small_problem(U, I, T, d, seed=9)
@@ -377,6 +425,7 @@ def test_frontend_main_runs_through_cf_c(tmp_path, capsys):
     cfg = yaml.safe_load(open("heat_amd/cf/benchmarks/Gowalla/MF_CCL/configs/config_pr1.yaml"))
     cfg["model_config"]["epochs"] = 3
     cfg["model_config"]["eval_interval"] = 2
+    cfg["model_config"]["use_aggregator"] = bool(accl)
     path = tmp_path / "cfg.yaml"
     path.write_text(yaml.safe_dump(cfg))
     r_dense = cf_main.main(["--config", str(path), "--synthetic", "gowalla", "--scale", "0.1"])
@@ -509,9 +558,11 @@ def test_randomized_serial_parity_sweep():
         assert np.abs(ig - io).max() <= 3e-4 * np.abs(io).max(), ctx
 
 
-def test_distributed_main_under_torchrun(tmp_path):
+@pytest.mark.parametrize("accl", [False, True])
+def test_distributed_main_under_torchrun(tmp_path, accl):
     """`torchrun -m heat_amd.cf.main --distributed`: the user-sharded trainer (device-mode engine on torch tensors, item
-    sync, loss and Recall reduced over ranks) end to end with one rank on this GPU (child process)."""
+    sync, loss and Recall reduced over ranks) end to end with one rank on this GPU (child process); with `accl` the
+    behaviour aggregator runs device-resident and its W0 joins the synchronised state."""
     import os
     import subprocess
     import sys
@@ -519,10 +570,11 @@ def test_distributed_main_under_torchrun(tmp_path):
     cfg = yaml.safe_load(open("heat_amd/cf/benchmarks/Gowalla/MF_CCL/configs/config_pr1.yaml"))
     cfg["model_config"]["epochs"] = 3
     cfg["model_config"]["eval_interval"] = 2
+    cfg["model_config"]["use_aggregator"] = bool(accl)
     path = tmp_path / "cfg.yaml"
     path.write_text(yaml.safe_dump(cfg))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
-           "--master-port", "29581", "-m", "heat_amd.cf.main", "--config", str(path), "--synthetic", "gowalla", "--scale", "0.1",
+           "--master-port", "29582" if accl else "29581", "-m", "heat_amd.cf.main", "--config", str(path), "--synthetic", "gowalla", "--scale", "0.1",
            "--distributed"]
     res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=280,
                          env=dict(os.environ, MASTER_ADDR="127.0.0.1"))
@@ -531,4 +583,4 @@ def test_distributed_main_under_torchrun(tmp_path):
     losses = [float(l.split("loss:")[1].split(";")[0]) for l in out.splitlines() if l.startswith("epoch:")]
     assert len(losses) == 3 and losses[2] < losses[0]
     rec = [float(l.split("Recall(k=20):")[1]) for l in out.splitlines() if l.startswith("[Metrics]")]
-    assert rec and 0.02 < rec[-1] < 1.0
+    assert rec and (0.005 if accl else 0.02) < rec[-1] < 1.0
