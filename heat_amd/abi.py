@@ -206,7 +206,7 @@ class Engine:
                                             _ptr(masks), _ptr(user_w), _ptr(item_w), _ptr(w0), C.byref(self._h)))
 
     def close(self):
-        if getattr(self, "_h", None) is not None and self._h:
+        if getattr(self, "_h", None) is not None and self._h and load is not None:   # load is None at interpreter teardown
             load().heat_cf_engine_destroy(self._h)
             self._h = C.c_void_p()
 
