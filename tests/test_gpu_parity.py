@@ -425,7 +425,6 @@ def test_frontend_main_runs_through_cf_c(tmp_path, capsys):
     cfg = yaml.safe_load(open("heat_amd/cf/benchmarks/Gowalla/MF_CCL/configs/config_pr1.yaml"))
     cfg["model_config"]["epochs"] = 3
     cfg["model_config"]["eval_interval"] = 2
-    cfg["model_config"]["use_aggregator"] = bool(accl)
     path = tmp_path / "cfg.yaml"
     path.write_text(yaml.safe_dump(cfg))
     r_dense = cf_main.main(["--config", str(path), "--synthetic", "gowalla", "--scale", "0.1"])
