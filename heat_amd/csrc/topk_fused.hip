@@ -114,20 +114,49 @@ __device__ __forceinline__ void push(Shared& s, uint32_t u, uint32_t item, float
     }
 }
 
-// acc[a][c] += a-row value * b-row pair, product and sum rounded separately
-__device__ __forceinline__ void tile_step(const Shared& s, int kq, int tx, int ty, f2 (&acc)[4][4])
+// operands of one k step: 4 user values (broadcast over the 16 lanes of a row) and 8 item values
+struct StepOps { f4 av, b0, b1; };
+
+__device__ __forceinline__ StepOps tile_fetch(const Shared& s, int kq, int tx, int ty)
 {
-    const f4 av = *(const f4*)&s.a[kq][ty * 4];
-    const f4 b0 = *(const f4*)&s.b[kq][tx * 4];
-    const f4 b1 = *(const f4*)&s.b[kq][64 + tx * 4];
+    StepOps o;
+    o.av = *(const f4*)&s.a[kq][ty * 4];
+    o.b0 = *(const f4*)&s.b[kq][tx * 4];
+    o.b1 = *(const f4*)&s.b[kq][64 + tx * 4];
+    return o;
+}
+
+// acc[a][c] += a-row value * b-row pair, product and sum rounded separately
+__device__ __forceinline__ void tile_fma(const StepOps& o, f2 (&acc)[4][4])
+{
 #pragma unroll
     for (int a = 0; a < 4; ++a)
     {
-        const f2 aa = f2{av[a], av[a]};
-        acc[a][0] = acc[a][0] + aa * f2{b0[0], b0[1]};
-        acc[a][1] = acc[a][1] + aa * f2{b0[2], b0[3]};
-        acc[a][2] = acc[a][2] + aa * f2{b1[0], b1[1]};
-        acc[a][3] = acc[a][3] + aa * f2{b1[2], b1[3]};
+        const f2 aa = f2{o.av[a], o.av[a]};
+        acc[a][0] = acc[a][0] + aa * f2{o.b0[0], o.b0[1]};
+        acc[a][1] = acc[a][1] + aa * f2{o.b0[2], o.b0[3]};
+        acc[a][2] = acc[a][2] + aa * f2{o.b1[0], o.b1[1]};
+        acc[a][3] = acc[a][3] + aa * f2{o.b1[2], o.b1[3]};
+    }
+}
+
+__device__ __forceinline__ void tile_step(const Shared& s, int kq, int tx, int ty, f2 (&acc)[4][4])
+{
+    tile_fma(tile_fetch(s, kq, tx, ty), acc);
+}
+
+// a full slab with the LDS reads of step k+1 in flight while step k multiplies
+__device__ __forceinline__ void tile_slab(const Shared& s, int tx, int ty, f2 (&acc)[4][4])
+{
+    StepOps cur = tile_fetch(s, 0, tx, ty);
+#pragma unroll
+    for (int kq = 0; kq < KS; ++kq)
+    {
+        StepOps nxt = cur;
+        if (kq + 1 < KS) nxt = tile_fetch(s, kq + 1, tx, ty);
+        __builtin_amdgcn_sched_barrier(0); // keep the fetch ahead of the arithmetic it overlaps with
+        tile_fma(cur, acc);
+        cur = nxt;
     }
 }
 
@@ -244,8 +273,7 @@ __global__ __launch_bounds__(256) void topk_fused_kernel(FusedArgs p)
             const int kmax = (d - k0) < (uint32_t)KS ? (int)(d - k0) : KS;
             if (kmax == KS)
             {
-#pragma unroll
-                for (int kq = 0; kq < KS; ++kq) tile_step(s, kq, tx, ty, acc);
+                tile_slab(s, tx, ty, acc);
             }
             else
             {
