@@ -172,16 +172,18 @@ struct FusedArgs
     uint32_t*       part_i;
 };
 
-// one float4 of user row u0+sr and of item rows i0+sr, i0+64+sr at columns [k0+sc, k0+sc+4); zero outside the tables
-// (emb_dim % 4 == 0 and 16-byte aligned rows are checked on the host)
+// One float4 of user row u0+sr and of item rows i0+sr, i0+64+sr at columns [k0+sc, k0+sc+4).  No branches: rows past
+// the end of a table are clamped to its last row and columns past emb_dim to its last float4 — such scores are
+// computed but never ranked (the filter checks user < rows, item < num_items; the k loop stops at emb_dim).
+// emb_dim % 4 == 0 and 16-byte aligned rows are checked on the host.
 __device__ __forceinline__ void load_slab(const FusedArgs& p, uint32_t u0, uint32_t i0, uint32_t k0, int sr, int sc,
                                           f4& ga, f4& gb0, f4& gb1)
 {
-    const uint32_t kk = k0 + (uint32_t)sc, d = p.d;
-    ga = gb0 = gb1 = f4{0, 0, 0, 0};
-    if (u0 + sr < p.rows && kk < d) ga = *(const f4*)(p.U + (size_t)(u0 + sr) * d + kk);
-    if (i0 + sr < p.num_items && kk < d) gb0 = *(const f4*)(p.V + (size_t)(i0 + sr) * d + kk);
-    if (i0 + 64 + sr < p.num_items && kk < d) gb1 = *(const f4*)(p.V + (size_t)(i0 + 64 + sr) * d + kk);
+    const uint32_t d = p.d, kk = min(k0 + (uint32_t)sc, d - 4u);
+    const uint32_t last = p.num_items - 1u;
+    ga  = *(const f4*)(p.U + ((size_t)min(u0 + (uint32_t)sr, p.rows - 1u) * d + kk));
+    gb0 = *(const f4*)(p.V + ((size_t)min(i0 + (uint32_t)sr, last) * d + kk));
+    gb1 = *(const f4*)(p.V + ((size_t)min(i0 + 64u + (uint32_t)sr, last) * d + kk));
 }
 
 __global__ __launch_bounds__(256) void topk_fused_kernel(FusedArgs p)
