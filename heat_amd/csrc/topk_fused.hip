@@ -32,12 +32,13 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 
 constexpr int QW = 128;    // candidate queue entries per wave and tile
 
-struct __attribute__((aligned(16))) Shared
+// CAP = list slots per user (32 or 64): the short form leaves room for a fourth workgroup per CU
+template <int CAP> struct __attribute__((aligned(16))) SharedT
 {
     float    a[KS][LDA];
     float    b[KS][LDB];
-    float    topv[TU][TOPK_FUSED_MAX_K]; // per user: the k best so far, best first
-    uint32_t topi[TU][TOPK_FUSED_MAX_K];
+    float    topv[TU][CAP]; // per user: the k best so far, best first
+    uint32_t topi[TU][CAP];
     float    thr_v[TU];                  // = entry k-1, the one a candidate has to beat
     uint32_t thr_i[TU];
     uint32_t mbits[TU][4];
@@ -55,7 +56,7 @@ __device__ __forceinline__ int owner(uint32_t u) { return (int)((u >> 2) & 3u); 
 
 // One candidate for local user u, handled by a whole wave: lane l < k owns list slot l.  The entries ahead of the
 // candidate are a prefix of the sorted list, so its position is a ballot + popcount and the tail moves down one slot.
-__device__ __forceinline__ void insert(Shared& s, uint32_t u, uint32_t item, float v, uint32_t k, int lane)
+template <class Shared> __device__ __forceinline__ void insert(Shared& s, uint32_t u, uint32_t item, float v, uint32_t k, int lane)
 {
     // threshold and list slots are fetched together: one LDS round trip per candidate
     const bool have = (uint32_t)lane < k;
@@ -86,7 +87,7 @@ __device__ __forceinline__ void insert(Shared& s, uint32_t u, uint32_t item, flo
 }
 
 // every wave empties its own queue: 64 entries are fetched at once, then handed out lane by lane
-__device__ __forceinline__ void drain(Shared& s, uint32_t k, int wave, int lane)
+template <class Shared> __device__ __forceinline__ void drain(Shared& s, uint32_t k, int wave, int lane)
 {
     const uint32_t n = min(s.qn[wave], (uint32_t)QW);
     for (uint32_t base = 0; base < n; base += 64)
@@ -102,7 +103,7 @@ __device__ __forceinline__ void drain(Shared& s, uint32_t k, int wave, int lane)
     }
 }
 
-__device__ __forceinline__ void push(Shared& s, uint32_t u, uint32_t item, float v)
+template <class Shared> __device__ __forceinline__ void push(Shared& s, uint32_t u, uint32_t item, float v)
 {
     const int w = owner(u);
     const uint32_t slot = atomicAdd(&s.qn[w], 1u);
@@ -117,7 +118,7 @@ __device__ __forceinline__ void push(Shared& s, uint32_t u, uint32_t item, float
 // operands of one k step: 4 user values (broadcast over the 16 lanes of a row) and 8 item values
 struct StepOps { f4 av, b0, b1; };
 
-__device__ __forceinline__ StepOps tile_fetch(const Shared& s, int kq, int tx, int ty)
+template <class Shared> __device__ __forceinline__ StepOps tile_fetch(const Shared& s, int kq, int tx, int ty)
 {
     StepOps o;
     o.av = *(const f4*)&s.a[kq][ty * 4];
@@ -140,13 +141,13 @@ __device__ __forceinline__ void tile_fma(const StepOps& o, f2 (&acc)[4][4])
     }
 }
 
-__device__ __forceinline__ void tile_step(const Shared& s, int kq, int tx, int ty, f2 (&acc)[4][4])
+template <class Shared> __device__ __forceinline__ void tile_step(const Shared& s, int kq, int tx, int ty, f2 (&acc)[4][4])
 {
     tile_fma(tile_fetch(s, kq, tx, ty), acc);
 }
 
 // a full slab with the LDS reads of step k+1 in flight while step k multiplies
-__device__ __forceinline__ void tile_slab(const Shared& s, int tx, int ty, f2 (&acc)[4][4])
+template <class Shared> __device__ __forceinline__ void tile_slab(const Shared& s, int tx, int ty, f2 (&acc)[4][4])
 {
     StepOps cur = tile_fetch(s, 0, tx, ty);
 #pragma unroll
@@ -186,8 +187,9 @@ __device__ __forceinline__ void load_slab(const FusedArgs& p, uint32_t u0, uint3
     gb1 = *(const f4*)(p.V + ((size_t)min(i0 + 64u + (uint32_t)sr, last) * d + kk));
 }
 
-__global__ __launch_bounds__(256) void topk_fused_kernel(FusedArgs p)
+template <int CAP> __global__ __launch_bounds__(256, CAP == 32 ? 4 : 3) void topk_fused_kernel(FusedArgs p)
 {
+    typedef SharedT<CAP> Shared;
     __shared__ Shared s;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tx = tid & 15, ty = tid >> 4;
@@ -197,7 +199,7 @@ __global__ __launch_bounds__(256) void topk_fused_kernel(FusedArgs p)
     const uint32_t t_end = min(ntiles, t_begin + p.tiles_per_split);
     const uint32_t d = p.d, k = p.k;
 
-    for (int t = tid; t < TU * TOPK_FUSED_MAX_K; t += 256)
+    for (int t = tid; t < TU * CAP; t += 256)
     {
         (&s.topv[0][0])[t] = -INFINITY;
         (&s.topi[0][0])[t] = NONE;
@@ -424,7 +426,8 @@ hipError_t launch_topk_fused(const float* user_rows, const float* item_w, uint32
     p.tiles_per_split = (ntiles + splits - 1) / splits;
     if ((uint64_t)p.tiles_per_split * (splits - 1) >= ntiles && splits > 1) return hipErrorInvalidValue; // empty split
     p.indptr = indptr; p.items = items; p.part_v = part_v; p.part_i = part_i;
-    hipLaunchKernelGGL(topk_fused_kernel, dim3((rows + TU - 1) / TU, splits), dim3(256), 0, s, p);
+    if (k <= 32) hipLaunchKernelGGL(topk_fused_kernel<32>, dim3((rows + TU - 1) / TU, splits), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(topk_fused_kernel<64>, dim3((rows + TU - 1) / TU, splits), dim3(256), 0, s, p);
     hipError_t err = hipGetLastError();
     if (err != hipSuccess) return err;
     hipLaunchKernelGGL(topk_merge_kernel, dim3(rows), dim3(64), 0, s, part_v, part_i, rows, k, splits, topk);
