@@ -95,10 +95,18 @@ def main():
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X (no CPU fallback)")
     abi.load()
+    # HEAT_BENCH_BACKEND=gloo rehearses the N>1 code path with several ranks on ONE GPU (RCCL refuses two ranks on a
+    # device; gloo stages the all-reduce through the host).  Its numbers mean nothing; it only has to run through.
+    backend = os.environ.get("HEAT_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1 or "RANK" in os.environ:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     # one side stream carries everything: engine kernels, the torch element-wise ops of the item sync and (through
     # torch.distributed's stream hand-off) the RCCL all-reduce are ordered with respect to each other

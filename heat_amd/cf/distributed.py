@@ -58,7 +58,7 @@ class ItemSync:
     data_rows) through epochs cut into windows, all-reducing `item_w` (a torch tensor aliasing the engine's table)."""
 
     def __init__(self, engine, item_w, world_size, refresh_interval=8192, sync_interactions=0, mode="sum", streams=0,
-                 force_collective=False, mean_tensors=()):
+                 force_collective=False, mean_tensors=(), negatives=None):
         import torch.distributed as dist
         self.dist = dist
         self.engine = engine
@@ -66,6 +66,7 @@ class ItemSync:
         self.world = world_size
         self.mode = mode
         self.mean_tensors = tuple(mean_tensors)   # replicated small state averaged at every sync (aggregator W0)
+        self.negatives = negatives                # [data_rows, num_negs] u64 fed instead of the on-GPU sampler (parity tests)
         if sync_interactions <= 0:
             streams = streams or getattr(engine, "num_streams", 0) or 3022
             sync_interactions = streams * refresh_interval
@@ -118,7 +119,10 @@ class ItemSync:
             lo = min(n, w * window)
             hi = min(n, (w + 1) * window)
             if hi > lo:
-                got = e.train_range(lo, hi, want_loss=self.track_loss)
+                if self.negatives is None:
+                    got = e.train_range(lo, hi, want_loss=self.track_loss)
+                else:
+                    got = e.train_range(lo, hi, self.negatives[lo:hi], want_loss=self.track_loss)
                 if self.track_loss:
                     loss_sum += got
             self.sync()
@@ -137,6 +141,7 @@ class ShardedTrainer:
 
     Behaviour aggregation (ACCL): pass `his` [num_users, max_his] u64, `masks` [num_users] u64 and `w0` [d, d] f32; the
     history rows follow their users into the shard, W0 is replicated and averaged at every sync.
+    `negatives` [len(clicks), num_negs] u64 replaces the on-GPU sampler with caller-fed ids (parity tests).
 
     `engine_factory(shard_clicks, user_w_shard_tensor, item_w_tensor, sample_index_base)` may replace the HIP engine
     (the CPU tests plug the oracle in that way); with aggregation it is also handed `his=, masks=, w0=` (shard rows,
@@ -144,7 +149,7 @@ class ShardedTrainer:
 
     def __init__(self, clicks, user_w, item_w, *, num_negs, rank=None, world_size=None, device=None, seed=2022,
                  refresh_interval=8192, sync_interactions=0, mode="sum", engine_factory=None, balance="users",
-                 his=None, masks=None, w0=None, **cfg_kwargs):
+                 his=None, masks=None, w0=None, negatives=None, **cfg_kwargs):
         import torch
         import torch.distributed as dist
         self.torch = torch
@@ -202,7 +207,9 @@ class ShardedTrainer:
                 self.engine = engine_factory(self.shard, self.t_user, self.t_item, base)
         self.sync = ItemSync(self.engine, self.t_item, self.world, refresh_interval=refresh_interval,
                              sync_interactions=sync_interactions, mode=mode,
-                             mean_tensors=(self.t_w0,) if self.aggregate else ())
+                             mean_tensors=(self.t_w0,) if self.aggregate else (),
+                             negatives=None if negatives is None else
+                             np.ascontiguousarray(negatives[base:base + self.shard.shape[0]], dtype=np.uint64))
 
     def train_one_epoch(self, want_loss=False):
         """One epoch on this rank's shard.  want_loss=True returns the GLOBAL mean loss (loss sums and interaction counts

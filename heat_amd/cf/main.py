@@ -35,8 +35,15 @@ def _main_distributed(args, model_config, cf_config, train_data, test_data, seed
     import torch.distributed as dist
     from .distributed import ShardedTrainer
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # HEAT_CF_DIST_BACKEND=gloo: several ranks share one GPU (tests; RCCL refuses two ranks on a device)
+    backend = os.environ.get("HEAT_CF_DIST_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
-    dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        dist.init_process_group(backend)
     rank, world = dist.get_rank(), dist.get_world_size()
     agg = {}
     if getattr(cf_config, "use_aggregator", False):             # ACCL: history rows follow their users, W0 is replicated

@@ -557,11 +557,13 @@ def test_randomized_serial_parity_sweep():
         assert np.abs(ig - io).max() <= 3e-4 * np.abs(io).max(), ctx
 
 
-@pytest.mark.parametrize("accl", [False, True])
-def test_distributed_main_under_torchrun(tmp_path, accl):
+@pytest.mark.parametrize("accl,nproc", [(False, 1), (True, 1), (False, 2), (True, 2)])
+def test_distributed_main_under_torchrun(tmp_path, accl, nproc):
     """`torchrun -m heat_amd.cf.main --distributed`: the user-sharded trainer (device-mode engine on torch tensors, item
     sync, loss and Recall reduced over ranks) end to end with one rank on this GPU (child process); with `accl` the
-    behaviour aggregator runs device-resident and its W0 joins the synchronised state."""
+    behaviour aggregator runs device-resident and its W0 joins the synchronised state.  nproc=2 puts two ranks on this one
+    GPU with the gloo backend (RCCL refuses two ranks per device): real HIP engines on real shards, windows agreed
+    across ranks, item table (and W0) all-reduced, loss and Recall reduced over ranks."""
     import os
     import subprocess
     import sys
@@ -572,14 +574,55 @@ def test_distributed_main_under_torchrun(tmp_path, accl):
     cfg["model_config"]["use_aggregator"] = bool(accl)
     path = tmp_path / "cfg.yaml"
     path.write_text(yaml.safe_dump(cfg))
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
-           "--master-port", "29582" if accl else "29581", "-m", "heat_amd.cf.main", "--config", str(path), "--synthetic", "gowalla", "--scale", "0.1",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
+           "--master-port", str(29581 + int(accl) + 2 * (nproc - 1)), "-m", "heat_amd.cf.main", "--config", str(path), "--synthetic", "gowalla", "--scale", "0.1",
            "--distributed"]
     res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=280,
-                         env=dict(os.environ, MASTER_ADDR="127.0.0.1"))
+                         env=dict(os.environ, MASTER_ADDR="127.0.0.1", **({"HEAT_CF_DIST_BACKEND": "gloo"} if nproc > 1 else {})))
     out = res.stdout
     assert res.returncode == 0, out[-3000:]
     losses = [float(l.split("loss:")[1].split(";")[0]) for l in out.splitlines() if l.startswith("epoch:")]
     assert len(losses) == 3 and losses[2] < losses[0]
     rec = [float(l.split("Recall(k=20):")[1]) for l in out.splitlines() if l.startswith("[Metrics]")]
     assert rec and (0.005 if accl else 0.02) < rec[-1] < 1.0
+
+
+def test_two_ranks_on_one_gpu_equal_single_process_training(tmp_path):
+    """The multi-GPU path with real HIP engines: two ranks (gloo; both on this GPU, RCCL refuses two ranks per device)
+    train their user shards in windows of 64 interactions and all-reduce the item table after every window.  The shards
+    touch disjoint item rows, so the `sum` rule must reproduce single-process training of the whole list (oracle), the
+    replicas must agree bit for bit, and the all-gathered user table must be the concatenation of the shards."""
+    import os
+    import subprocess
+    import sys
+    rng = np.random.default_rng(0)
+    U, I, d, N, T, epochs = 40, 200, 64, 4, 600, 2
+    users = np.sort(rng.integers(0, U, T))
+    half = U // 2
+    pos = np.where(users < half, rng.integers(0, I // 2, T), rng.integers(I // 2, I, T))
+    negs = np.where((users < half)[:, None], rng.integers(0, I // 2, (T, N)), rng.integers(I // 2, I, (T, N))).astype(np.uint64)
+    clicks = np.stack([users, pos], axis=1).astype(np.uint64)
+    uw = (rng.standard_normal((U, d)) * 0.1).astype(np.float32)
+    iw = (rng.standard_normal((I, d)) * 0.1).astype(np.float32)
+    np.savez(tmp_path / "problem.npz", clicks=clicks, negs=negs, uw=uw, iw=iw, num_negs=N, lr=0.01, epochs=epochs)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29591", os.path.join(os.path.dirname(__file__), "_gpu_shard_worker.py"), str(tmp_path), "64"]
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=280,
+                         env=dict(os.environ, MASTER_ADDR="127.0.0.1"))
+    assert res.returncode == 0 and res.stdout.count("SHARD_OK") == 2, res.stdout[-3000:]
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    assert np.array_equal(r0["iw"], r1["iw"])
+    u1, i1 = uw.copy(), iw.copy()
+    ref = orc.Engine(clicks, u1, i1, num_negs=N, l_r=0.01, clip_val=1.0)
+    want_losses = []
+    for _ in range(epochs):
+        ref.lr_step()
+        want_losses.append(ref.train_range(0, T, negs) / T)
+        ref.zero_grad()
+        ref.epoch = ref.epoch + 1
+    got_u = np.concatenate([r0["uw"], r1["uw"]])
+    assert np.array_equal(r0["full_u"], got_u) and np.array_equal(r1["full_u"], got_u)
+    assert_tables_close(r0["iw"], i1, scale=np.abs(i1).max(), rtol=2e-4)
+    assert_tables_close(got_u, u1, scale=np.abs(u1).max(), rtol=2e-4)
+    np.testing.assert_allclose(r0["losses"], want_losses, rtol=1e-4)      # global mean loss, reduced over the two ranks
+    np.testing.assert_array_equal(r0["losses"], r1["losses"])
