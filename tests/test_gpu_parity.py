@@ -479,7 +479,7 @@ def test_device_mode_engine_with_item_sync_on_a_side_stream():
     import sys
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29571")
     res = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "_gpu_sync_worker.py")],
-                         env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=280)
+                         env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
     assert res.returncode == 0 and "SYNC_OK" in res.stdout, res.stdout[-3000:]
 
 
@@ -577,7 +577,7 @@ def test_distributed_main_under_torchrun(tmp_path, accl, nproc):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
            "--master-port", str(29581 + int(accl) + 2 * (nproc - 1)), "-m", "heat_amd.cf.main", "--config", str(path), "--synthetic", "gowalla", "--scale", "0.1",
            "--distributed"]
-    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=280,
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900,
                          env=dict(os.environ, MASTER_ADDR="127.0.0.1", **({"HEAT_CF_DIST_BACKEND": "gloo"} if nproc > 1 else {})))
     out = res.stdout
     assert res.returncode == 0, out[-3000:]
@@ -607,7 +607,7 @@ def test_two_ranks_on_one_gpu_equal_single_process_training(tmp_path):
     np.savez(tmp_path / "problem.npz", clicks=clicks, negs=negs, uw=uw, iw=iw, num_negs=N, lr=0.01, epochs=epochs)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
            "--master-port", "29591", os.path.join(os.path.dirname(__file__), "_gpu_shard_worker.py"), str(tmp_path), "64"]
-    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=280,
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900,
                          env=dict(os.environ, MASTER_ADDR="127.0.0.1"))
     assert res.returncode == 0 and res.stdout.count("SHARD_OK") == 2, res.stdout[-3000:]
     r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
