@@ -26,6 +26,8 @@ ap.add_argument("--seeds", type=str, default="2022")
 ap.add_argument("--clusters", type=int, default=0)
 ap.add_argument("--lr", type=float, default=0.01)
 ap.add_argument("--agg", action="store_true", help="behaviour aggregation (ACCL) on both sides")
+ap.add_argument("--tile", action="store_true", help="random-tile negative sampler (neg_sampler 1, tile 512, refresh 8192; the "
+                "`sampling` call, random_tile_negative_sampler.cpp:31-45) on both sides")
 args = ap.parse_args()
 
 g, d, N = synthetic.make_named(args.shape, scale=args.scale, n_clusters=args.clusters)
@@ -60,8 +62,10 @@ for seed in [int(x) for x in args.seeds.split(",")]:
         for streams in [int(x) for x in args.streams.split(",")]:
             uw, iw = uw0.copy(), iw0.copy()
             agg_kw = dict(his=his, masks=masks, w0=w00.copy(), use_aggregator=True) if args.agg else {}
-            eng = abi.Engine(g.clicks, uw, iw, num_negs=N, seed=seed, **agg_kw, coherence=coh, num_streams=streams, clip_val=args.clip, l_r=args.lr,
-                             flags=abi.FLAG_LAZY_SYNC, update_mode=upd)
+            tile_kw = dict(neg_sampler=1, tile_size=512, refresh_interval=8192) if args.tile else {}
+            eng = abi.Engine(g.clicks, uw, iw, num_negs=N, seed=seed, **agg_kw, **tile_kw, coherence=coh, num_streams=streams,
+                             clip_val=args.clip, l_r=args.lr, update_mode=upd,
+                             flags=abi.FLAG_LAZY_SYNC | (abi.FLAG_SAMPLING_CALL if args.tile else 0))
             t0 = time.time()
             losses = [eng.train_one_epoch() for _ in range(args.epochs)]
             dt = time.time() - t0
@@ -74,9 +78,10 @@ for seed in [int(x) for x in args.seeds.split(",")]:
     for th in [int(x) for x in args.oracle_threads.split(",")]:
         uo, io = uw0.copy(), iw0.copy()
         agg_kw = dict(his=his, masks=masks, w0=w00.copy(), use_aggregator=True) if args.agg else {}
-        ora = orc.Engine(g.clicks, uo, io, num_negs=N, clip_val=args.clip, l_r=args.lr, **agg_kw)
+        tile_kw = dict(neg_sampler=1, tile_size=512, refresh_interval=8192) if args.tile else {}
+        ora = orc.Engine(g.clicks, uo, io, num_negs=N, clip_val=args.clip, l_r=args.lr, **agg_kw, **tile_kw)
         t0 = time.time()
-        losses = [ora.train_one_epoch(num_threads=th) for _ in range(args.epochs)]
+        losses = [ora.train_one_epoch(num_threads=th, sampler_call=1 if args.tile else 0) for _ in range(args.epochs)]
         dt = time.time() - t0
         print(f"ORACLE seed={seed} threads={th}: losses={[round(x, 4) for x in losses]} ({dt:.1f}s, "
               f"{g.clicks.shape[0] * args.epochs / dt / 1e3:.1f} k samples/s)", flush=True)
