@@ -170,7 +170,7 @@ def main():
 
     traffic = None
     pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if os.path.exists(pmc_path) and args.shape == "amazonbooks":
+    if os.path.exists(pmc_path) and args.shape == "amazonbooks" and args.update_mode == 0:
         # HBM bytes per launch from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same command
         # (tools/pmc_traffic.py; counters cannot be collected from inside the process being timed)
         with open(pmc_path) as f:
