@@ -469,6 +469,38 @@ def test_full_size_properties_amazonbooks_shape():
     eng.close()
 
 
+def test_topk_full_size_properties_amazonbooks_shape():
+    """Size-independent properties of the fused top-k at the full AmazonBooks size (52 643 users x 91 599 items, the matrix
+    the reference's evaluate0 materialises in 19.3 GB): (a) no train item is ever returned; (b) the ids of a row are
+    distinct and in range; (c) for sampled users the returned ids are exactly the oracle's top-20 of the masked dense
+    row, in the same order; (d) user sub-ranges and a second call return the same ids (no state between calls)."""
+    g, d, N = synthetic.make_named("amazonbooks", with_test=False)
+    uw, iw = synthetic.init_embeddings(g.num_users, g.num_items, d, seed=11, std=0.1)
+    eng = abi.Engine(g.clicks[:1].copy(), uw, iw, num_negs=N)
+    top = eng.topk(20, mask_indptr=g.train_indptr, mask_items=g.train_items)
+    assert top.shape == (g.num_users, 20) and top.max() < g.num_items
+    srt = np.sort(top, axis=1)
+    assert (srt[:, 1:] != srt[:, :-1]).all()                                         # (b)
+    indptr, items = g.train_indptr.astype(np.int64), g.train_items
+    seen = np.zeros(g.num_items, dtype=bool)
+    rng = np.random.default_rng(0)
+    sample = np.concatenate([[0, g.num_users - 1], rng.integers(0, g.num_users, 2000)])
+    for u in sample:                                                                 # (a) on 2002 users
+        seen[:] = False
+        seen[items[indptr[u]:indptr[u + 1]]] = True
+        assert not seen[top[u]].any()
+    one = orc.Engine(g.clicks[:1].copy(), uw[:1].copy(), iw.copy(), num_negs=N)
+    for u in sample[:40]:                                                            # (c)
+        one.user_w[0] = uw[u]
+        row = one.evaluate0()[0]
+        row[items[indptr[u]:indptr[u + 1]]] = -np.inf
+        assert np.array_equal(top[u], np.argsort(-row, kind="stable")[:20].astype(np.uint32)), u
+    lo, hi = g.num_users // 3, g.num_users // 3 + 1000
+    assert np.array_equal(eng.topk(20, u_begin=lo, u_end=hi, mask_indptr=g.train_indptr, mask_items=g.train_items), top[lo:hi])
+    assert np.array_equal(eng.topk(20, mask_indptr=g.train_indptr, mask_items=g.train_items), top)    # (d)
+    eng.close()
+
+
 def test_device_mode_engine_with_item_sync_on_a_side_stream():
     """Device mode (torch tensors handed over as raw pointers, engine launching on a torch side stream) + the item-table
     sync path of heat_amd.cf.distributed with a 1-rank RCCL group: `W <- ref + allreduce(W - ref)` must be the identity,
