@@ -797,7 +797,10 @@ static int topk_fused(heat_cf_engine* e, uint64_t u_begin, uint64_t u_end, uint3
         return std::chrono::duration<double, std::milli>(b - a).count();
     };
     const auto t_start = now();
-    const uint64_t panel = std::min<uint64_t>(nu, 1ull << 20);
+    uint64_t panel_cap = 1ull << 20;
+    if (const char* pc = getenv("HEAT_CF_TOPK_PANEL")) // tests: walk several user panels with a small table
+        panel_cap = std::max<uint64_t>(1, strtoull(pc, nullptr, 10));
+    const uint64_t panel = std::min<uint64_t>(nu, panel_cap);
     const uint32_t slots = 3 * e->cu_count; // 3 workgroups of 52 KB LDS per CU
     const uint64_t last = nu % panel ? nu % panel : panel;
     const size_t part_elems = (size_t)k * std::max<uint64_t>(panel * topk_fused_splits((uint32_t)panel, (uint32_t)I, slots),

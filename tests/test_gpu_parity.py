@@ -382,6 +382,9 @@ def test_topk_fused_matches_numpy_and_panel_path(U, I, d, k, case, monkeypatch):
     assert np.array_equal(nomask, _topk_want(ref, None, None, k))
     sub = eng.topk(k, mask_indptr=indptr, mask_items=items, u_begin=U // 2, u_end=U)
     assert np.array_equal(sub, got[U // 2:])
+    monkeypatch.setenv("HEAT_CF_TOPK_PANEL", "37")           # users walked in panels of 37: same ids
+    assert np.array_equal(eng.topk(k, mask_indptr=indptr, mask_items=items), got)
+    monkeypatch.delenv("HEAT_CF_TOPK_PANEL")
     monkeypatch.setenv("HEAT_CF_TOPK_PATH", "panel")
     assert np.array_equal(eng.topk(k, mask_indptr=indptr, mask_items=items), got)
     eng.close()
