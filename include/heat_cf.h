@@ -137,8 +137,10 @@ int heat_cf_engine_create(const heat_cf_config* cfg, const uint64_t* clicks, uin
                           float* item_w, float* w0, heat_cf_engine** out);
 
 /* Device-mode twin: every pointer is a DEVICE pointer owned by the caller (clicks still u64 pairs, they are
- * packed to u32 pairs into engine-owned memory and range-checked on the GPU).  `stream` is a hipStream_t
- * (NULL = the engine creates its own non-blocking stream). */
+ * packed to u32 pairs into engine-owned memory and range-checked on the GPU; with use_aggregator != 0 the same
+ * holds for d_his [num_users,max_his] u64 and d_masks [num_users] u64, and d_w0 [emb_dim,emb_dim] fp32 is trained
+ * in place — the form a multi-GPU caller uses to all-reduce W0, train/engine.cpp:355-359).  `stream` is a
+ * hipStream_t (NULL = the engine creates its own non-blocking stream). */
 int heat_cf_engine_create_device(const heat_cf_config* cfg, const void* d_clicks, uint64_t data_rows,
                                  const void* d_his, uint64_t max_his, const void* d_masks, void* d_user_w,
                                  void* d_item_w, void* d_w0, void* stream, heat_cf_engine** out);
@@ -170,9 +172,11 @@ int heat_cf_sample_negatives(heat_cf_engine* e, uint64_t begin, uint64_t end, ui
  * sim[num_users,num_items] = U * V^T, fp32, written to HOST memory. */
 int heat_cf_evaluate0(heat_cf_engine* e, float* sim);
 
-/* Fused evaluate0 + train-mask + top-k (metrics.py:21-29): for users [u_begin,u_end) writes
- * the k best item ids (descending score) to HOST topk[(u_end-u_begin), k] u32.  mask_indptr/mask_items is the
- * CSR of train items per user (HOST, may be NULL = no masking). */
+/* Fused evaluate0 + train-mask + top-k (train/engine.cpp:388-400 + metrics.py:21-29): for users
+ * [u_begin,u_end) writes the k best item ids (descending score, ties by ascending id, masked items last) to HOST
+ * topk[(u_end-u_begin), k] u32.  mask_indptr [num_users+1] / mask_items is the CSR of train items per user (HOST, may
+ * be NULL = no masking; rows need not be sorted).  Scores are the fp32 dots evaluate0 returns, bit for bit; for
+ * k <= 64 they are never stored (no [users, items] matrix), larger k goes through score panels. */
 int heat_cf_topk(heat_cf_engine* e, uint64_t u_begin, uint64_t u_end, uint32_t k, const uint64_t* mask_indptr,
                  const uint32_t* mask_items, uint32_t* topk);
 
