@@ -141,8 +141,13 @@ int make_plan(const heat_cf_config* cfg, uint64_t data_rows, uint64_t fill, Plan
     p->coherence = coh;
     // streams: enough sequential walkers to fill the chip, but never more asynchrony than was validated against the
     // oracle at AmazonBooks shape: 3072 streams x 17 item rows in flight over 91 599 item rows = 0.56 in-flight touches
-    // per item row (and 5.8 % of the users in flight)
-    p->cap_items = (uint32_t)std::min<uint64_t>(0xFFFFFFFFull, (uint64_t)(0.56 * (double)cfg->num_items / (double)(cfg->num_negs + 1)));
+    // per item row (and 5.8 % of the users in flight).  What an interaction suffers is the number of ITS rows another
+    // stream changes while it is in flight, in-flight touches x (num_negs + 1): measured epoch-loss lag against the
+    // oracle grows with that product (Yelp18 shape, 65 rows: +9 % at 0.56, +3 % at 0.15;
+    // profiles/r01_recall_parity_yelp18_yaml_clip.txt), so above 17 rows per interaction the bound shrinks with it.
+    const double rows_per_interaction = (double)(cfg->num_negs + 1);
+    const double in_flight = 0.56 * std::min(1.0, 17.0 / rows_per_interaction);
+    p->cap_items = (uint32_t)std::min<uint64_t>(0xFFFFFFFFull, (uint64_t)(in_flight * (double)cfg->num_items / rows_per_interaction));
     p->cap_users = (uint32_t)std::min<uint64_t>(0xFFFFFFFFull, (uint64_t)(0.058 * (double)cfg->num_users));
     uint64_t streams = std::min<uint64_t>(p->cap_items, p->cap_users);
     if (fill) streams = std::min(streams, fill);
