@@ -56,7 +56,9 @@ def _main_distributed(args, model_config, cf_config, train_data, test_data, seed
     trainer = ShardedTrainer(train_data.click_dataset, user_w, item_w, num_negs=cf_config.num_negs, seed=seed,
                              clip_val=cf_config.clip_val, l_r=cf_config.l_r, milestones=tuple(cf_config.milestones),
                              refresh_interval=cf_config.refresh_interval, neg_sampler=cf_config.neg_sampler,
-                             tile_size=cf_config.tile_size, **agg)
+                             tile_size=cf_config.tile_size,
+                             sync_interactions=int(model_config.get('sync_interactions', 0)),   # 0: streams x refresh_interval, capped at one epoch
+                             **agg)
     lo, hi = trainer.lo, trainer.hi
     indptr, items = train_data.train_csr()
     local_indptr = (indptr[lo:hi + 1] - indptr[lo]).astype(np.uint64)
