@@ -225,7 +225,8 @@ int common_init(heat_cf_engine* e, const heat_cf_config* cfg, uint64_t data_rows
     if (prc) return prc;
     e->auto_streams = plan.streams;
     e->upd = (int)plan.upd_bits;
-    std::snprintf(e->kname, sizeof(e->kname), "ccl_train_kernel<%d,%d,%d,%d>/upd=0x%x", e->lpr, e->ng, e->aux, e->nw, (unsigned)e->upd);
+    std::snprintf(e->kname, sizeof(e->kname), "ccl_train_kernel<%d,%d,%d,%d>/upd=0x%x/streams=%u", e->lpr, e->ng, e->aux, e->nw,
+                  (unsigned)e->upd, (unsigned)plan.streams);
     HIP_TRY(hipMalloc(&e->d_sums, 2 * sizeof(double)));
     HIP_TRY(hipMemsetAsync(e->d_sums, 0, 2 * sizeof(double), e->stream));
     HIP_TRY(hipMalloc(&e->d_stats, 4 * sizeof(uint32_t)));

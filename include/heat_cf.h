@@ -94,8 +94,9 @@ typedef struct heat_cf_config
     uint32_t coherence;         /* HEAT_CF_COHERENCE_* */
     int32_t  device;            /* HIP device ordinal; -1 = current device */
     uint32_t num_streams;       /* concurrent sequential interaction streams (workgroups); 0 = auto: what fills the GPU,
-                                   capped at 0.56 * num_items / (num_negs + 1) and 5.8 % of num_users (the asynchrony
-                                   validated against the oracle at AmazonBooks shape) */
+                                   capped at 0.56 * num_items / (num_negs + 1) — times 17 / (num_negs + 1) above 17 rows
+                                   per interaction — and 5.8 % of num_users (the asynchrony validated against the
+                                   oracle at AmazonBooks and Yelp18 shape) */
     uint32_t update_mode;       /* HEAT_CF_UPDATE_* */
 } heat_cf_config;
 
