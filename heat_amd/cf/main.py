@@ -58,6 +58,7 @@ def _main_distributed(args, model_config, cf_config, train_data, test_data, seed
                              refresh_interval=cf_config.refresh_interval, neg_sampler=cf_config.neg_sampler,
                              tile_size=cf_config.tile_size,
                              sync_interactions=int(model_config.get('sync_interactions', 0)),   # 0: streams x refresh_interval, capped at one epoch
+                             num_streams=int(cf_config.num_streams), update_mode=int(cf_config.update_mode),
                              **agg)
     lo, hi = trainer.lo, trainer.hi
     indptr, items = train_data.train_csr()
@@ -107,7 +108,10 @@ def main(argv=None):
                          tile_size=model_config['tile_size'], refresh_interval=model_config['refresh_interval'],
                          l2=model_config['embedding_regularizer'], clip_val=model_config['clip_val'],
                          milestones=model_config['milestones'], l_r=model_config['learning_rate'], seed=seed,
-                         use_aggregator=bool(model_config.get('use_aggregator', False)))
+                         use_aggregator=bool(model_config.get('use_aggregator', False)),
+                         # optional extension keys (absent from the reference's yaml): 0 = the engine's own choice
+                         num_streams=int(model_config.get('num_streams', 0)),
+                         update_mode=int(model_config.get('update_mode', 0)))
     print('--- Start loading data ---')
     if args.synthetic:
         graph, _, _ = synthetic.make_named(args.synthetic, seed=seed, scale=args.scale)
