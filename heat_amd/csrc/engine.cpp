@@ -132,7 +132,8 @@ struct Plan
 };
 
 // fill = workgroups the chip can keep resident for the chosen variant (from the occupancy query; 0 = unknown: caps only)
-int make_plan(const heat_cf_config* cfg, uint64_t data_rows, uint64_t fill, Plan* p)
+// history_rows = rows an interaction reads besides user / positive / negatives (max_his with behaviour aggregation)
+int make_plan(const heat_cf_config* cfg, uint64_t data_rows, uint64_t fill, Plan* p, uint64_t history_rows = 0)
 {
     int rc = validate_cfg(cfg, data_rows, &p->lpr, &p->ng, &p->nw);
     if (rc) return rc;
@@ -145,8 +146,10 @@ int make_plan(const heat_cf_config* cfg, uint64_t data_rows, uint64_t fill, Plan
     // stream changes while it is in flight, in-flight touches x (num_negs + 1): measured epoch-loss lag against the
     // oracle grows with that product (Yelp18 shape, 65 rows: +9 % at 0.56, +3 % at 0.15;
     // profiles/r01_recall_parity_yelp18_yaml_clip.txt), so above 17 rows per interaction the bound shrinks with it.
+    // Behaviour aggregation also reads up to max_his history rows whose staleness enters the same way (AmazonBooks shape,
+    // profiles/r01_recall_parity_accl_streams2.txt: Recall@20 within 1e-3 of the oracle up to 640 streams, -2e-3 at 1024).
     const double rows_per_interaction = (double)(cfg->num_negs + 1);
-    const double in_flight = 0.56 * std::min(1.0, 17.0 / rows_per_interaction);
+    const double in_flight = 0.56 * std::min(1.0, 17.0 / (rows_per_interaction + (double)history_rows));
     p->cap_items = (uint32_t)std::min<uint64_t>(0xFFFFFFFFull, (uint64_t)(in_flight * (double)cfg->num_items / rows_per_interaction));
     p->cap_users = (uint32_t)std::min<uint64_t>(0xFFFFFFFFull, (uint64_t)(0.058 * (double)cfg->num_users));
     uint64_t streams = std::min<uint64_t>(p->cap_items, p->cap_users);
@@ -177,7 +180,7 @@ int make_plan(const heat_cf_config* cfg, uint64_t data_rows, uint64_t fill, Plan
     return HEAT_CF_OK;
 }
 
-int common_init(heat_cf_engine* e, const heat_cf_config* cfg, uint64_t data_rows, void* stream)
+int common_init(heat_cf_engine* e, const heat_cf_config* cfg, uint64_t data_rows, void* stream, uint64_t history_rows = 0)
 {
     e->cfg = *cfg;
     e->milestones.assign(cfg->milestones, cfg->milestones + cfg->n_milestones);
@@ -215,13 +218,13 @@ int common_init(heat_cf_engine* e, const heat_cf_config* cfg, uint64_t data_rows
         e->own_stream = true;
     }
     Plan plan;
-    int prc = make_plan(cfg, data_rows, 0, &plan);       // variant + coherence first: the occupancy query needs them
+    int prc = make_plan(cfg, data_rows, 0, &plan, history_rows);       // variant + coherence first: the occupancy query needs them
     if (prc) return prc;
     e->aux = plan.coherence == HEAT_CF_COHERENCE_DEVICE ? 16 : 0;
     // resident workgroups per CU as the runtime reports them for this variant (register / LDS limited)
     int per_cu = query_blocks_per_cu(e->lpr, e->ng, e->nw, e->aux, cfg->use_aggregator != 0, (uint32_t)cfg->emb_dim);
     if (per_cu < 1) per_cu = 1;
-    prc = make_plan(cfg, data_rows, (uint64_t)e->cu_count * (uint64_t)per_cu, &plan);
+    prc = make_plan(cfg, data_rows, (uint64_t)e->cu_count * (uint64_t)per_cu, &plan, history_rows);
     if (prc) return prc;
     e->auto_streams = plan.streams;
     e->upd = (int)plan.upd_bits;
@@ -468,7 +471,7 @@ int heat_cf_engine_create(const heat_cf_config* cfg, const uint64_t* clicks, uin
             return _rc;             \
         }                           \
     } while (0)
-    CREATE_TRY(common_init(e, cfg, data_rows, nullptr));
+    CREATE_TRY(common_init(e, cfg, data_rows, nullptr, cfg->use_aggregator ? max_his : 0));
     auto body = [&]() -> int {
         e->own_tables = true;
         HIP_TRY(hipMalloc(&e->d_user_w, std::max<size_t>(user_bytes(e), 16)));
@@ -526,7 +529,7 @@ int heat_cf_engine_create_device(const heat_cf_config* cfg, const void* d_clicks
     e->ng = ng;
     e->nw = nw;
     e->host_mode = false;
-    CREATE_TRY(common_init(e, cfg, data_rows, stream));
+    CREATE_TRY(common_init(e, cfg, data_rows, stream, cfg->use_aggregator ? max_his : 0));
     auto body = [&]() -> int {
         e->own_tables = false;
         e->d_user_w = (float*)d_user_w;
