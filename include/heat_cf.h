@@ -119,7 +119,9 @@ int         heat_cf_abi_version(void);
 const char* heat_cf_last_error(void);
 /* Launch plan the engine would use for `cfg` — kernel variant, coherence, number of streams (asynchrony cap) and update
  * policy — as a small JSON object written to `out`.  Pure host logic, no GPU needed; `resident_workgroups` is what the
- * chip keeps resident for the variant (0 = unknown: only the caps apply). */
+ * chip keeps resident for the variant (0 = unknown: only the caps apply).  With use_aggregator != 0 an engine also
+ * counts max_his history rows per interaction in the stream bound, which this call cannot know: read the engine's own
+ * choice from heat_cf_kernel_name (".../streams=N"). */
 int         heat_cf_plan(const heat_cf_config* cfg, uint64_t data_rows, uint64_t resident_workgroups, char* out,
                          uint64_t out_bytes);
 /* number of visible HIP devices, or a negative error code */
