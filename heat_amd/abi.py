@@ -40,7 +40,7 @@ class DeviceView(C.Structure):
                 ("w0", C.c_void_p), ("clicks", C.c_void_p), ("data_rows", C.c_uint64), ("stream", C.c_void_p)]
 
 
-# every symbol include/heat_cf.h declares (tests/test_abi_symbols.py checks the header against this list)
+# every symbol include/heat_cf.h declares (tests/test_frontend_cpu.py::test_abi_exports_every_declared_symbol checks the header against this list)
 SYMBOLS = {
     "heat_cf_abi_version": (C.c_int, []),
     "heat_cf_last_error": (C.c_char_p, []),
@@ -62,6 +62,8 @@ SYMBOLS = {
     "heat_cf_sync_to_host": (C.c_int, [C.c_void_p]),
     "heat_cf_sync_from_host": (C.c_int, [C.c_void_p]),
     "heat_cf_synchronize": (C.c_int, [C.c_void_p]),
+    "heat_cf_sync_delta": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "heat_cf_sync_apply": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float]),
     "heat_cf_get_device_view": (C.c_int, [C.c_void_p, C.POINTER(DeviceView)]),
     "heat_cf_copy_to_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
     "heat_cf_epoch": (C.c_uint64, [C.c_void_p]),
@@ -259,6 +261,17 @@ class Engine:
 
     def synchronize(self):
         _check(load().heat_cf_synchronize(self._h))
+
+    def sync_delta(self, ref_ptr, mine_ptr, sum_ptr):
+        """mine = sum = W_item - ref (device pointers; asynchronous on the engine's stream)."""
+        _check(load().heat_cf_sync_delta(self._h, C.c_void_p(ref_ptr), C.c_void_p(mine_ptr) if mine_ptr else None,
+                                         C.c_void_p(sum_ptr)))
+
+    def sync_apply(self, ref_ptr, sum_ptr, mine_ptr, scale=1.0):
+        """W_item += scale * sum - mine; ref += scale * sum; mine_ptr=None: W_item = ref = ref + scale * sum
+        (device pointers; asynchronous on the engine's stream)."""
+        _check(load().heat_cf_sync_apply(self._h, C.c_void_p(ref_ptr), C.c_void_p(sum_ptr),
+                                         C.c_void_p(mine_ptr) if mine_ptr else None, scale))
 
     def zero_grad(self):
         _check(load().heat_cf_zero_grad(self._h))

@@ -55,11 +55,26 @@ def shard_clicks(clicks, num_users, world_size, rank, bounds=None):
 
 class ItemSync:
     """Drives `engine` (heat_amd.abi.Engine in device mode, or any object with begin_epoch / train_range / end_epoch /
-    data_rows) through epochs cut into windows, all-reducing `item_w` (a torch tensor aliasing the engine's table)."""
+    data_rows) through epochs cut into windows and exchanges the replicated item table `item_w` (a torch tensor aliasing
+    the engine's table) between the ranks.
+
+    One exchange = delta (`sum = mine = W - ref`) -> all-reduce(`sum`) -> apply.  With an abi.Engine the two element-wise
+    passes are the fused HIP kernels behind heat_cf_sync_delta / heat_cf_sync_apply; with any other engine (the CPU tests
+    plug the oracle in) they are the same arithmetic in torch.
+
+    overlap=False: every exchange is completed before the next window starts (`W = ref = ref + scale * sum`, bit-identical
+    replicas after every window).
+    overlap=True : the all-reduce of window k runs while window k+1 trains (asynchronous collective; torch.distributed
+    orders it after the delta kernel and makes the training stream wait for it only at the next exchange); the other
+    ranks' deltas then arrive one window late (`W += scale * sum - mine`).  The LAST exchange of an epoch is completed
+    before the epoch ends, so the replicas are bit-identical at every epoch boundary — unless defer_final=True, which
+    lets it overlap the first window of the next epoch (steady-state throughput runs; call finalize() before reading
+    the table)."""
 
     def __init__(self, engine, item_w, world_size, refresh_interval=8192, sync_interactions=0, mode="sum", streams=0,
-                 force_collective=False, mean_tensors=(), negatives=None):
-        import torch.distributed as dist
+                 force_collective=False, mean_tensors=(), negatives=None, overlap=False, defer_final=False, dist=None):
+        if dist is None:
+            import torch.distributed as dist
         self.dist = dist
         self.engine = engine
         self.item_w = item_w
@@ -72,31 +87,83 @@ class ItemSync:
             sync_interactions = streams * refresh_interval
         self.window = max(1, int(sync_interactions))   # clamped to the LARGEST shard inside train_one_epoch (same on every rank)
         self.force = bool(force_collective)     # run the collective path even with one rank (tests)
-        self.ref = item_w.clone() if (mode == "sum" and (world_size > 1 or self.force)) else None
-        self._n_max = None
-        self.track_loss = False   # True: train_range synchronises per window and the local loss sum is returned
         if mode not in ("sum", "mean"):
             raise ValueError("mode must be 'sum' or 'mean'")
+        self.scale = 1.0 if mode == "sum" else 1.0 / world_size
+        self.active = world_size > 1 or self.force
+        self.overlap = bool(overlap) and self.active
+        self.defer_final = bool(defer_final) and self.overlap
+        self.native = hasattr(engine, "sync_delta") and getattr(item_w, "is_cuda", False)
+        self.ref = item_w.clone() if self.active else None
+        self.sum = item_w.clone() if self.active else None
+        self.mine = item_w.clone() if self.overlap else None
+        self.pending = None                      # (work handle) of an all-reduce in flight
+        self._n_max = None
+        self.exchanges = 0
+        self.track_loss = False   # True: train_range synchronises per window and the local loss sum is returned
 
     def describe(self):
-        return {"collective": "all_reduce(item table)" + (" + all_reduce(W0)" if self.mean_tensors else ""), "mode": self.mode,
+        return {"collective": "all_reduce(item table delta)" + (" + all_reduce(W0)" if self.mean_tensors else ""), "mode": self.mode,
+                "overlap": self.overlap, "fused_delta_apply_kernels": bool(self.native),
                 "window_interactions_per_gpu": min(self.window, self.engine.data_rows)}
 
-    def sync(self):
-        if self.world == 1 and not self.force:
+    # ---- the two element-wise passes --------------------------------------------------------------------------------
+    def _delta(self, with_mine):
+        if self.native:
+            self.engine.sync_delta(self.ref.data_ptr(), self.mine.data_ptr() if with_mine else 0, self.sum.data_ptr())
+        else:
+            self.sum.copy_(self.item_w).sub_(self.ref)
+            if with_mine:
+                self.mine.copy_(self.sum)
+
+    def _apply(self, with_mine):
+        if self.native:
+            self.engine.sync_apply(self.ref.data_ptr(), self.sum.data_ptr(), self.mine.data_ptr() if with_mine else 0, self.scale)
+        elif with_mine:
+            self.sum.mul_(self.scale)
+            self.item_w.add_(self.sum).sub_(self.mine)
+            self.ref.add_(self.sum)
+        else:
+            self.ref.add_(self.sum, alpha=self.scale)
+            self.item_w.copy_(self.ref)
+
+    def _complete(self):
+        """Wait for the all-reduce in flight (stream-side for RCCL, host-side for gloo) and apply it."""
+        if self.pending is None:
             return
+        work, with_mine = self.pending
+        if work is not None:
+            work.wait()
+        self._apply(with_mine)
+        self.pending = None
+
+    def _post(self, blocking):
+        """Start an exchange of everything this rank changed since the reference."""
+        self._complete()                        # the reference must be current before the next delta
         for t in self.mean_tensors:
             self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
             t.div_(self.world)
-        if self.mode == "mean":
-            self.dist.all_reduce(self.item_w, op=self.dist.ReduceOp.SUM)
-            self.item_w.div_(self.world)
-        else:
-            # delta since the last sync, summed over ranks, applied to the common reference
-            self.item_w.sub_(self.ref)
-            self.dist.all_reduce(self.item_w, op=self.dist.ReduceOp.SUM)
-            self.item_w.add_(self.ref)
-            self.ref.copy_(self.item_w)
+        with_mine = not blocking
+        self._delta(with_mine)
+        work = self.dist.all_reduce(self.sum, op=self.dist.ReduceOp.SUM, async_op=not blocking)
+        self.pending = (work if not blocking else None, with_mine)
+        self.exchanges += 1
+        if blocking:
+            self._complete()
+
+    def sync(self, last=True):
+        if not self.active:
+            return
+        self._post(blocking=not self.overlap or (last and not self.defer_final))
+
+    def finalize(self):
+        """Complete an exchange left in flight by defer_final (replicas still differ by their last window: follow with a
+        blocking exchange to make them identical)."""
+        if not self.active:
+            return
+        self._complete()
+        if self.defer_final:
+            self._post(blocking=True)
 
     def train_one_epoch(self):
         e = self.engine
@@ -125,7 +192,7 @@ class ItemSync:
                     got = e.train_range(lo, hi, self.negatives[lo:hi], want_loss=self.track_loss)
                 if self.track_loss:
                     loss_sum += got
-            self.sync()
+            self.sync(last=(w == n_windows - 1))
         e.end_epoch()
         return loss_sum if self.track_loss else None
 
@@ -149,7 +216,7 @@ class ShardedTrainer:
 
     def __init__(self, clicks, user_w, item_w, *, num_negs, rank=None, world_size=None, device=None, seed=2022,
                  refresh_interval=8192, sync_interactions=0, mode="sum", engine_factory=None, balance="users",
-                 his=None, masks=None, w0=None, negatives=None, **cfg_kwargs):
+                 his=None, masks=None, w0=None, negatives=None, overlap=False, defer_final=False, **cfg_kwargs):
         import torch
         import torch.distributed as dist
         self.torch = torch
@@ -207,7 +274,7 @@ class ShardedTrainer:
                 self.engine = engine_factory(self.shard, self.t_user, self.t_item, base)
         self.sync = ItemSync(self.engine, self.t_item, self.world, refresh_interval=refresh_interval,
                              sync_interactions=sync_interactions, mode=mode,
-                             mean_tensors=(self.t_w0,) if self.aggregate else (),
+                             mean_tensors=(self.t_w0,) if self.aggregate else (), overlap=overlap, defer_final=defer_final,
                              negatives=None if negatives is None else
                              np.ascontiguousarray(negatives[base:base + self.shard.shape[0]], dtype=np.uint64))
 

@@ -111,7 +111,8 @@ __device__ __forceinline__ void buf_store(__amdgpu_buffer_rsrc_t rsrc, uint32_t 
 // philox(counter = {slot, 0, idx_lo, idx_hi}, key = {seed_lo, seed_hi}) equals
 //   hiprand_init(seed, /*subsequence*/ idx, /*offset*/ 4 * slot, &st); hiprand4(&st)
 // (rocrand_philox4x32_10.h: seed() sets the key, discard_subsequence adds to counter.zw, discard(4*slot) adds
-// slot to counter.xy).  tests/test_sampler_gpu.py checks this identity on the GPU against hiprand_kernel.h.
+// slot to counter.xy).  Checked on the GPU against hiprand_kernel.h itself: oracle/hiprand_kat.hip +
+// tests/test_gpu_parity.py::test_philox_equals_hiprand_device_api.
 __device__ __forceinline__ uint64_t philox_draw64(uint32_t slot, uint64_t idx, uint64_t seed)
 {
     uint32_t c0 = slot, c1 = 0u, c2 = (uint32_t)idx, c3 = (uint32_t)(idx >> 32);

@@ -97,6 +97,85 @@ __device__ __forceinline__ void dup_rotations(uint32_t id, bool& hit)
     dup_rot_step<13>(id, hit); dup_rot_step<14>(id, hit); dup_rot_step<15>(id, hit);
 }
 
+// ---- multi-wave workgroups (NW > 1): every wave draws ALL negative slots of the interaction itself ---------------------
+// Lane k, register v holds slot v*64 + k.  The ~100-instruction generator is cheaper than sharing ids through LDS: no
+// barrier, and every wave can count the multiplicity of ITS slots against all ids with one compare + ballot per slot
+// instead of a num_negs-iteration scan.  The draws do not depend on table data, so the kernel evaluates them for the
+// NEXT interaction in the shadow of the current gather.
+template <int NIDA>
+__device__ __forceinline__ void draw_all_ids(const TrainArgs& a, uint64_t idx, uint32_t pos, uint64_t first, int lane,
+                                             uint32_t (&nid)[NIDA])
+{
+#pragma unroll
+    for (int v = 0; v < NIDA; ++v)
+    {
+        const uint32_t slot = (uint32_t)(v * 64 + lane);
+        uint32_t id;
+        if (a.ext_negs != nullptr)
+        {
+            id = slot < a.num_negs ? a.ext_negs[(idx - a.ext_base) * a.num_negs + slot] : 0u;
+        }
+        else
+        {
+            if (a.tile_size != 0u && a.sampling_call)
+                id = tile_item(slot, a.sample_base + idx, a.key, blockIdx.x, idx - first, a.tile_size, a.refresh_interval,
+                               a.num_items);
+            else
+                id = uniform_item(philox_draw64(slot, a.sample_base + idx, a.key), a.num_items);
+            if (!a.sampling_call && id == pos) id = nid[v];      // ignore_pos_sampling keeps the previous id
+        }
+        nid[v] = id;
+    }
+}
+
+// mult[g] = (copies of this lane's row id among all slots) | (copies in EARLIER slots) << 16 for the slot (g, rr) this lane
+// serves; returns the largest multiplicity among the wave's slots (wave-uniform).
+template <int NIDA, int NGW, int R>
+__device__ __forceinline__ uint32_t slot_multiplicity(const uint32_t (&nid)[NIDA], uint32_t N, uint32_t wave_base, int lane,
+                                                      int rr, uint32_t (&mult)[NGW])
+{
+    uint32_t cmax = 1u;
+#pragma unroll
+    for (int g = 0; g < NGW; ++g)
+    {
+        mult[g] = 1u;
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+        {
+            const uint32_t gslot = wave_base + (uint32_t)(g * R + r);          // wave-uniform
+            if (gslot < N)
+            {
+                uint32_t sid = 0u;
+#pragma unroll
+                for (int v = 0; v < NIDA; ++v)
+                    if ((int)(gslot >> 6) == v) sid = (uint32_t)__builtin_amdgcn_readlane((int)nid[v], (int)(gslot & 63u));
+                uint64_t same[NIDA];
+                uint32_t eq = 0u;
+#pragma unroll
+                for (int v = 0; v < NIDA; ++v)
+                {
+                    same[v] = __builtin_amdgcn_ballot_w64(nid[v] == sid && (uint32_t)(v * 64 + lane) < N);
+                    eq += (uint32_t)__builtin_popcountll(same[v]);
+                }
+                if (eq > 1u)                                                     // rare, wave-uniform
+                {
+                    uint32_t earlier = 0u;
+#pragma unroll
+                    for (int v = 0; v < NIDA; ++v)
+                    {
+                        const uint32_t lo = (uint32_t)(v * 64);
+                        const uint64_t below = gslot >= lo + 64u ? ~0ull : (gslot <= lo ? 0ull : ((1ull << (gslot - lo)) - 1ull));
+                        earlier += (uint32_t)__builtin_popcountll(same[v] & below);
+                    }
+                    if (rr == r) mult[g] = eq | (earlier << 16);
+                    cmax = eq > cmax ? eq : cmax;
+                }
+            }
+        }
+    }
+    return cmax;
+}
+
 template <int LPR, int AUX>
 __device__ __forceinline__ void flush_user_row(const TrainArgs& a, uint32_t user, bool cut, f32x4 u4, f32x4 gu4, f32x4 u4_in,
                                                f32x4 gu4_in, float* tile, int lane, int rr, bool col_ok, uint32_t col_off)
@@ -126,7 +205,8 @@ __device__ __forceinline__ void flush_user_row(const TrainArgs& a, uint32_t user
 // NW waves form one workgroup and share ONE interaction stream: wave w owns the negative slots
 // [w*NGW*R, (w+1)*NGW*R); user and positive rows are replicated in every wave's registers (every wave computes the
 // identical update of them, wave 0 writes them back).  Softmax statistics and the user-gradient partial sums cross
-// waves through LDS (2-3 workgroup barriers per interaction).  NW = 1 compiles all of that away.
+// waves through LDS (two workgroup barriers per interaction: softmax statistics, user-gradient partials); every wave
+// draws all negative ids itself (no id exchange).  NW = 1 compiles all of that away.
 //
 // AGG = true adds the reference's behaviour aggregation (behavior_aggregators/behavior_aggregators.cpp:51-153, called
 // unconditionally at matrix_factorization.cpp:38,152): u <- 0.4 u + 0.6 (mean of the user's history item rows) W0, in
@@ -134,7 +214,13 @@ __device__ __forceinline__ void flush_user_row(const TrainArgs& a, uint32_t user
 // applied every 32 calls (W0 -= lr * acc/32, here by float atomic adds on the shared W0), and g_u *= 0.4.
 // The stream keeps a private LDS copy of W0 (refreshed after each of its own W0 updates) and the last <= 32
 // (means, 0.6 g_u) pairs; the accumulation order of the reference (call by call) is preserved when the pairs are summed.
-template <int LPR, int NGW, int AUX, int NW, bool AGG>
+//
+// RR = true ("late re-read", a.upd_bits bit 4): a negative row's W is read a second time together with its G row, a few
+// groups ahead of its update in the backward sweep, and the update is applied to THAT value (W_fresh - lr*G_new).  The
+// gradient itself is still the one of the forward pass.  This shrinks the read-modify-write window of a negative row
+// from the whole interaction (gather -> softmax -> sweep) to one memory round trip, i.e. the share of negative updates
+// lost to a concurrent writer by the same factor, without the memory-side atomic rate.
+template <int LPR, int NGW, int AUX, int NW, bool AGG, bool RR = false>
 __global__ __launch_bounds__(64 * NW) void ccl_train_kernel(TrainArgs a)
 {
     static_assert(!AGG || NW == 1, "behaviour aggregation is built for single-wave workgroups");
@@ -144,6 +230,7 @@ __global__ __launch_bounds__(64 * NW) void ccl_train_kernel(TrainArgs a)
     constexpr int R = 64 / LPR;            // rows fetched by one wave instruction
     constexpr int WCAP = NGW * R;          // negative slots held by one wave
     constexpr int NIDV = (WCAP + 63) / 64; // id registers per lane (lane k, register v: slot wave_base + v*64 + k)
+    constexpr int NIDA = NW > 1 ? (NW * WCAP + 63) / 64 : 1; // NW > 1: every wave holds ALL slots (lane k, register v: slot v*64 + k)
     // how many groups ahead the G rows are fetched in the backward sweep: a short look-ahead keeps the read-modify-write
     // window of a negative's G row small (fewer Hogwild collisions) where rows are small and hot; the multi-wave
     // variants (large rows, large tables) fetch deep to cover HBM latency
@@ -172,7 +259,6 @@ __global__ __launch_bounds__(64 * NW) void ccl_train_kernel(TrainArgs a)
         last = align_to_user_run(a.clicks, last, a.begin, a.end, a.align_cap, lane);
     }
     __shared__ __attribute__((aligned(16))) float tile_all[NW * 256]; // per-wave transpose tile for the atomics
-    __shared__ uint32_t sh_ids[NW > 1 ? NW * WCAP : 1];               // all negative ids of the interaction
     __shared__ float sh_stat[NW > 1 ? NW * 2 : 1];                    // per-wave (max, sum of exp)
     __shared__ __attribute__((aligned(16))) float sh_gu[NW > 1 ? NW * 64 * 4 : 4]; // per-wave user-gradient partials
     __shared__ float sh_slg[NW > 1 ? NW : 1];
@@ -208,6 +294,12 @@ __global__ __launch_bounds__(64 * NW) void ccl_train_kernel(TrainArgs a)
     uint32_t nid[NIDV];
 #pragma unroll
     for (int v = 0; v < NIDV; ++v) nid[v] = 0u; // engine.cpp:298: neg_ids zero-initialised per worker
+    // NW > 1: all slots in every wave, multiplicities of the wave's own slots, and the same for the NEXT interaction
+    uint32_t nid_all[NIDA], nxt_nid[NIDA], mult[NW > 1 ? NGW : 1], nxt_mult[NW > 1 ? NGW : 1];
+    uint32_t cmax_w = 1u, nxt_cmax = 1u;
+    bool have_next = false;
+#pragma unroll
+    for (int v = 0; v < NIDA; ++v) { nid_all[v] = 0u; nxt_nid[v] = 0u; }
     double loss_acc = 0.0;
     uint32_t raw_batch = 0u;               // raw draws of up to four interactions (BATCH4)
 
@@ -253,6 +345,28 @@ __global__ __launch_bounds__(64 * NW) void ccl_train_kernel(TrainArgs a)
                 nid[0] = id;
                 if (a.neg_out != nullptr && (uint32_t)lane < N) a.neg_out[(idx - a.neg_out_base) * N + (uint32_t)lane] = id;
             }
+            else if constexpr (NW > 1)
+            {
+                if (have_next)                       // drawn in the shadow of the previous interaction's gather
+                {
+#pragma unroll
+                    for (int v = 0; v < NIDA; ++v) nid_all[v] = nxt_nid[v];
+#pragma unroll
+                    for (int g = 0; g < NGW; ++g) mult[g] = nxt_mult[g];
+                    cmax_w = nxt_cmax;
+                }
+                else
+                {
+                    draw_all_ids<NIDA>(a, idx, pos, first, lane, nid_all);
+                    cmax_w = slot_multiplicity<NIDA, NGW, R>(nid_all, N, wave_base, lane, rr, mult);
+                }
+                if (a.neg_out != nullptr && wave == 0)
+                {
+#pragma unroll
+                    for (int v = 0; v < NIDA; ++v)
+                        if ((uint32_t)(v * 64 + lane) < N) a.neg_out[(idx - a.neg_out_base) * N + (uint32_t)(v * 64 + lane)] = nid_all[v];
+                }
+            }
             else
 #pragma unroll
             for (int v = 0; v < NIDV; ++v)
@@ -280,7 +394,6 @@ __global__ __launch_bounds__(64 * NW) void ccl_train_kernel(TrainArgs a)
                 }
                 nid[v] = id;
                 if (a.neg_out != nullptr && mine) a.neg_out[(idx - a.neg_out_base) * N + slot] = id;
-                if (NW > 1 && mine) sh_ids[slot] = id;
             }
 
             // ---- user row: registers while the user does not change (write back on change) -----------------
@@ -357,7 +470,22 @@ __global__ __launch_bounds__(64 * NW) void ccl_train_kernel(TrainArgs a)
             for (int g = 0; g < NGW; ++g)
             {
                 const int wk = g * R + rr;                   // slot of this lane's row inside the wave
-                const uint32_t id = lane_get(nid[(g * R) / 64], wk & 63);
+                uint32_t id;
+                if constexpr (NW > 1)
+                {
+                    const uint32_t gslot = wave_base + (uint32_t)wk;
+                    id = lane_get(nid_all[0], (int)(gslot & 63u));
+#pragma unroll
+                    for (int v = 1; v < NIDA; ++v)
+                    {
+                        const uint32_t t = lane_get(nid_all[v], (int)(gslot & 63u));
+                        id = (int)(gslot >> 6) == v ? t : id;
+                    }
+                }
+                else
+                {
+                    id = lane_get(nid[(g * R) / 64], wk & 63);
+                }
                 const bool valid = wave_base + (uint32_t)wk < N;
                 noff[g] = (valid && col_ok) ? id * a.row_bytes + col_off : OOB_OFF;
                 n4[g] = buf_load<AUX>(item_w, noff[g]);
@@ -369,10 +497,26 @@ __global__ __launch_bounds__(64 * NW) void ccl_train_kernel(TrainArgs a)
             // compute the identical c-fold result here, so whichever store lands last is the reference's value.
             uint32_t eq[NIDV], earlier[NIDV];
             uint32_t cmax = 1u;
+            if constexpr (NW > 1)
+            {
+                // multiplicities were counted with the draw; now, while the gather is in flight, draw the NEXT interaction
+                cmax = cmax_w;
+                have_next = (j + 1 < cnt);
+                if (have_next)
+                {
+                    const uint32_t pos_n = (uint32_t)__builtin_amdgcn_readlane((int)pair.y, j + 1);
+#pragma unroll
+                    for (int v = 0; v < NIDA; ++v) nxt_nid[v] = nid_all[v];
+                    draw_all_ids<NIDA>(a, idx + 1, pos_n, first, lane, nxt_nid);
+                    nxt_cmax = slot_multiplicity<NIDA, NGW, R>(nxt_nid, N, wave_base, lane, rr, nxt_mult);
+                }
+#pragma unroll
+                for (int v = 0; v < NIDV; ++v) { eq[v] = 0u; earlier[v] = 0u; }
+            }
+            else
             {
 #pragma unroll
                 for (int v = 0; v < NIDV; ++v) { eq[v] = 0u; earlier[v] = 0u; }
-                if (NW > 1) __syncthreads();                 // B1: every wave's ids are in sh_ids
                 // Fast rejection when the interaction's N <= 16 slots sit in one 16-lane DPP row (lanes 0..15 of a
                 // single-wave variant): 15 row rotations compare every pair; the counting scan below only runs when a
                 // duplicate exists (0.14 % of the interactions at AmazonBooks shape).
@@ -387,16 +531,9 @@ __global__ __launch_bounds__(64 * NW) void ccl_train_kernel(TrainArgs a)
                 for (uint32_t s = 0; need_scan && s < N; ++s)
                 {
                     uint32_t sid = 0u;
-                    if (NW > 1)
-                    {
-                        sid = sh_ids[s];
-                    }
-                    else
-                    {
 #pragma unroll
-                        for (int v = 0; v < NIDV; ++v)
-                            if ((int)(s >> 6) == v) sid = (uint32_t)__builtin_amdgcn_readlane((int)nid[v], (int)(s & 63u));
-                    }
+                    for (int v = 0; v < NIDV; ++v)
+                        if ((int)(s >> 6) == v) sid = (uint32_t)__builtin_amdgcn_readlane((int)nid[v], (int)(s & 63u));
 #pragma unroll
                     for (int v = 0; v < NIDV; ++v)
                     {
@@ -452,16 +589,14 @@ __global__ __launch_bounds__(64 * NW) void ccl_train_kernel(TrainArgs a)
             // the first G rows are requested here, so that their latency overlaps the softmax arithmetic; the rest follow
             // GPF groups ahead of their use in the backward sweep
             f32x4 gpf[GPF];                                             // G rows in flight
+            f32x4 wpf[RR ? GPF : 1];                                    // late re-read of the W rows (RR)
 #pragma unroll
-            for (int g = 0; g < GPF && g < NGW; ++g) gpf[g] = buf_load<AUX>(item_g, noff[g]);
-            mx = cross_max<LPR>(mx);
-            if (NW > 1)
+            for (int g = 0; g < GPF && g < NGW; ++g)
             {
-                if (lane == 0) sh_stat[wave * 2] = mx;
-                __syncthreads();                                        // B2a
-#pragma unroll
-                for (int w = 0; w < NW; ++w) mx = fmaxf(mx, sh_stat[w * 2]);
+                gpf[g] = buf_load<AUX>(item_g, noff[g]);
+                if (RR) wpf[g] = buf_load<AUX>(item_w, noff[g]);
             }
+            mx = cross_max<LPR>(mx);                                    // maximum over this wave's slots
             float ssum = 0.0f;
 #pragma unroll
             for (int g = 0; g < NGW; ++g)
@@ -472,11 +607,29 @@ __global__ __launch_bounds__(64 * NW) void ccl_train_kernel(TrainArgs a)
             ssum = cross_sum<LPR>(ssum);
             if (NW > 1)
             {
-                if (lane == 0) sh_stat[wave * 2 + 1] = ssum;
-                __syncthreads();                                        // B2b
-                ssum = 0.0f;
+                // ONE exchange: every wave publishes (its maximum, its sum of exp(score - its maximum)); the workgroup's
+                // maximum M and sum follow by rescaling with exp(m_w - M) (the streaming-softmax identity)
+                if (lane == 0)
+                {
+                    sh_stat[wave * 2] = mx;
+                    sh_stat[wave * 2 + 1] = ssum;
+                }
+                __syncthreads();                                        // B2
+                float big = -INFINITY;
 #pragma unroll
-                for (int w = 0; w < NW; ++w) ssum += sh_stat[w * 2 + 1];
+                for (int w = 0; w < NW; ++w) big = fmaxf(big, sh_stat[w * 2]);
+                float tot = 0.0f;
+#pragma unroll
+                for (int w = 0; w < NW; ++w)
+                {
+                    const float mw = sh_stat[w * 2];
+                    tot += (mw == -INFINITY) ? 0.0f : sh_stat[w * 2 + 1] * expf(mw - big);
+                }
+                const float scale = (mx == -INFINITY) ? 0.0f : expf(mx - big);
+#pragma unroll
+                for (int g = 0; g < NGW; ++g) es[g] *= scale;
+                mx = big;
+                ssum = tot;
             }
             // :106 adds exp(-max) computed in double; fp32 expf differs by <= 1 ulp of the sum
             const float Z = ssum + expf(-mx);
@@ -494,7 +647,12 @@ __global__ __launch_bounds__(64 * NW) void ccl_train_kernel(TrainArgs a)
             for (int g = 0; g < NGW; ++g)
             {
                 const f32x4 g_read = gpf[g % GPF];
-                if (g + GPF < NGW) gpf[g % GPF] = buf_load<AUX>(item_g, noff[g + GPF]);
+                const f32x4 w_base = RR ? wpf[RR ? g % GPF : 0] : n4[g];       // the W value the update is applied to
+                if (g + GPF < NGW)
+                {
+                    gpf[g % GPF] = buf_load<AUX>(item_g, noff[g + GPF]);
+                    if (RR) wpf[RR ? g % GPF : 0] = buf_load<AUX>(item_w, noff[g + GPF]);
+                }
                 const float lg = (es[g] * rcp_z) * score_mul;                   // :109
                 const float nnorm = fast_sqrt(nn[g] < eps ? eps : nn[g]);
                 const float nnorm3 = nnorm * nnorm * nnorm;
@@ -510,7 +668,7 @@ __global__ __launch_bounds__(64 * NW) void ccl_train_kernel(TrainArgs a)
                 if (cmax > 1u)                                                  // duplicates present (wave-uniform)
                 {
                     const int src = (g * R + rr) & 63;
-                    const uint32_t cm = lane_get(eq[(g * R) / 64], src);
+                    const uint32_t cm = NW > 1 ? (mult[NW > 1 ? g : 0] & 0xFFFFu) : lane_get(eq[(g * R) / 64], src);
                     for (uint32_t c = 1; c < cmax; ++c)
                     {
                         const f32x4 g2 = clip4(gn + t, clip);
@@ -519,21 +677,22 @@ __global__ __launch_bounds__(64 * NW) void ccl_train_kernel(TrainArgs a)
                     // only the first copy of a duplicated row writes its (c-fold) result: the reference's copies all
                     // write the same W_stale - lr*G_c / G_c (last writer wins = one effective update), and a later
                     // copy's streamed G fetch may already see the first copy's write
-                    if (lane_get(earlier[(g * R) / 64], src) != 0u) woff = OOB_OFF;
+                    const uint32_t before = NW > 1 ? (mult[NW > 1 ? g : 0] >> 16) : lane_get(earlier[(g * R) / 64], src);
+                    if (before != 0u) woff = OOB_OFF;
                 }
                 // a negative that equals the positive is not written: the positive's write-back comes last in the
                 // reference (matrix_factorization.cpp:171-174) and overwrites it
                 if (woff != OOB_OFF && woff - col_off == pos * a.row_bytes) woff = OOB_OFF;
                 if (!neg_w_atomic && !neg_g_atomic)
                 {
-                    buf_store<AUX>(item_w, woff, n4[g] - lr * gn);              // sgd.cpp:23, :148
+                    buf_store<AUX>(item_w, woff, w_base - lr * gn);             // sgd.cpp:23, :148
                     buf_store<AUX>(item_g, woff, gn);                           // :149
                 }
                 else
                 {
                     const AtomicOffsets ao = atomic_offsets(woff, lane);
                     if (neg_w_atomic) atomic_add_tile<4>(item_w, ao, -(lr * gn), tile, lane); // W += -(lr*G)
-                    else buf_store<AUX>(item_w, woff, n4[g] - lr * gn);
+                    else buf_store<AUX>(item_w, woff, w_base - lr * gn);
                     if (neg_g_atomic) atomic_add_tile<4>(item_g, ao, gn - g_read, tile, lane);
                     else buf_store<AUX>(item_g, woff, gn);
                 }
@@ -737,7 +896,12 @@ static hipError_t launch_variant(const TrainArgs& a, uint32_t grid, int aux, hip
             return hipErrorInvalidValue;
         }
     }
-    if (aux == AUX_PLAIN)
+    if (a.upd_bits & 16u)
+    {
+        if (aux != AUX_SC1) return hipErrorInvalidValue;            // a fresh value needs device-coherent loads
+        hipLaunchKernelGGL((ccl_train_kernel<LPR, NGW, AUX_SC1, NW, false, true>), dim3(grid), dim3(64 * NW), 0, s, a);
+    }
+    else if (aux == AUX_PLAIN)
         hipLaunchKernelGGL((ccl_train_kernel<LPR, NGW, AUX_PLAIN, NW, false>), dim3(grid), dim3(64 * NW), 0, s, a);
     else
         hipLaunchKernelGGL((ccl_train_kernel<LPR, NGW, AUX_SC1, NW, false>), dim3(grid), dim3(64 * NW), 0, s, a);
@@ -750,7 +914,7 @@ static hipError_t launch_variant(const TrainArgs& a, uint32_t grid, int aux, hip
 #define HEATCF_VARIANTS(X) \
     X(8, 1, 1) X(8, 2, 1) X(8, 4, 1) X(8, 8, 1) X(8, 16, 1) \
     X(16, 2, 1) X(16, 4, 1) X(16, 8, 1) X(16, 16, 1) X(16, 16, 2) \
-    X(32, 4, 1) X(32, 8, 1) X(32, 16, 1) X(32, 32, 1) X(32, 16, 2) X(32, 8, 4) X(32, 16, 4) \
+    X(32, 4, 1) X(32, 8, 1) X(32, 16, 1) X(32, 32, 1) X(32, 16, 2) X(32, 8, 4) X(32, 16, 4) X(32, 4, 8) X(32, 2, 16) \
     X(64, 8, 1) X(64, 16, 1) X(64, 16, 2) X(64, 16, 4) X(64, 25, 4) X(64, 13, 8) X(64, 16, 8)
 
 bool pick_variant(uint32_t emb_dim, uint32_t num_negs, bool single_wave, int* lpr_out, int* ng_out, int* nw_out)

@@ -52,6 +52,9 @@ hipError_t launch_pack_clicks(const uint64_t* in, uint2* out, uint64_t n, uint32
 hipError_t launch_pack_history(const uint64_t* his, const uint64_t* masks, uint32_t* his32, uint32_t* masks32,
                                uint64_t num_users, uint32_t max_his, uint64_t num_items, const uint2* clicks,
                                uint64_t data_rows, uint32_t* bad, hipStream_t s);
+// item_sync.hip
+hipError_t launch_item_delta(const float* w, const float* ref, float* mine, float* sum, size_t n_floats, hipStream_t s);
+hipError_t launch_item_apply(float* w, float* ref, const float* sum, const float* mine, float scale, size_t n_floats, hipStream_t s);
 hipError_t launch_sample_negs(const TrainArgs& a, uint32_t grid, uint64_t out_base, uint64_t* out, hipStream_t s);
 
 } // namespace heatcf

@@ -171,7 +171,7 @@ int make_plan(const heat_cf_config* cfg, uint64_t data_rows, uint64_t fill, Plan
     else if (um == HEAT_CF_UPDATE_ATOMIC_W) bits = 0x5u;
     else if (um == HEAT_CF_UPDATE_ATOMIC_WG) bits = 0xFu;
     else if (um == HEAT_CF_UPDATE_ATOMIC_POS) bits = 0xCu;
-    else if (um >= 16u && um < 32u) bits = um - 16u;
+    else if (um >= 16u && um < 48u) bits = um - 16u;
     else return fail(HEAT_CF_EINVAL, "bad update_mode");
     if (bits != 0u && coh != HEAT_CF_COHERENCE_DEVICE)
         return fail(HEAT_CF_EINVAL, "atomic update modes need HEAT_CF_COHERENCE_DEVICE");
@@ -960,6 +960,26 @@ int heat_cf_sync_from_host(heat_cf_engine* e)
     if (e->cfg.use_aggregator && e->h_w0 && e->d_w0)
         HIP_TRY(hipMemcpyAsync(e->d_w0, e->h_w0, (size_t)e->cfg.emb_dim * e->cfg.emb_dim * sizeof(float), hipMemcpyHostToDevice, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
+    return HEAT_CF_OK;
+}
+
+int heat_cf_sync_delta(heat_cf_engine* e, const void* d_ref, void* d_mine, void* d_sum)
+{
+    if (!e || !d_ref || !d_sum) return fail(HEAT_CF_EINVAL, "engine / buffer is NULL");
+    if (((uintptr_t)d_ref | (uintptr_t)d_mine | (uintptr_t)d_sum) & 15u) return fail(HEAT_CF_EINVAL, "buffers must be 16-byte aligned");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(launch_item_delta(e->d_item_w, (const float*)d_ref, (float*)d_mine, (float*)d_sum,
+                              (size_t)e->cfg.num_items * e->cfg.emb_dim, e->stream));
+    return HEAT_CF_OK;
+}
+
+int heat_cf_sync_apply(heat_cf_engine* e, void* d_ref, const void* d_sum, const void* d_mine, float scale)
+{
+    if (!e || !d_ref || !d_sum) return fail(HEAT_CF_EINVAL, "engine / buffer is NULL");
+    if (((uintptr_t)d_ref | (uintptr_t)d_mine | (uintptr_t)d_sum) & 15u) return fail(HEAT_CF_EINVAL, "buffers must be 16-byte aligned");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(launch_item_apply(e->d_item_w, (float*)d_ref, (const float*)d_sum, (const float*)d_mine, scale,
+                              (size_t)e->cfg.num_items * e->cfg.emb_dim, e->stream));
     return HEAT_CF_OK;
 }
 

@@ -65,7 +65,10 @@ extern "C" {
 #define HEAT_CF_UPDATE_AUTO       5 /* ATOMIC_POS while the expected number of concurrent touches of a negative row,
                                        streams * num_negs / num_items, is <= 0.56 (the regime validated against the
                                        oracle), ATOMIC_WG otherwise                                                   */
-/* values 16..31: raw policy bits (16 + bit0 neg W atomic + bit1 neg G atomic + bit2 pos W atomic + bit3 pos G atomic) */
+/* values 16..47: raw policy bits (16 + bit0 neg W atomic + bit1 neg G atomic + bit2 pos W atomic + bit3 pos G atomic
+ *                + bit4 "late re-read": a negative row's W is read again next to its G row just before its update and the
+ *                update is applied to that fresh value — the read-modify-write window of a negative row shrinks from
+ *                the whole interaction to one memory round trip; needs HEAT_CF_COHERENCE_DEVICE) */
 
 /* Replaces cf::modules::CFConfig (modules/cf_config.hpp:12-35; bound at pybind/init_modules.cpp:13-33).
  * The first 13 fields are the reference's, in its constructor order.  The rest are extensions the
@@ -186,6 +189,16 @@ int heat_cf_topk(heat_cf_engine* e, uint64_t u_begin, uint64_t u_end, uint32_t k
 /* host <-> device weight copies (host mode only; no-ops in device mode) */
 int heat_cf_sync_to_host(heat_cf_engine* e);
 int heat_cf_sync_from_host(heat_cf_engine* e);
+/* Multi-GPU item-table exchange, the two element-wise passes around the caller's collective (replaces the
+ * per-row MPI_Allreduce + "/ world_size" loop of train/engine.cpp:366-375).  All pointers are DEVICE buffers of
+ * num_items * emb_dim fp32 owned by the caller, 16-byte aligned; both calls are asynchronous on the engine's stream.
+ *   delta : mine = sum = W_item - ref                           (this rank's change since the common reference)
+ *   [caller all-reduces `sum` over the ranks — RCCL over xGMI — and may train the next window meanwhile]
+ *   apply : W_item += scale * sum - mine ;  ref += scale * sum   (scale 1: every rank's updates applied;
+ *                                                                  scale 1/world_size: replicas averaged, the fork's intent)
+ *           d_mine == NULL (nothing trained since `delta`): W_item = ref = ref + scale * sum, bit-identical on every rank */
+int heat_cf_sync_delta(heat_cf_engine* e, const void* d_ref, void* d_mine, void* d_sum);
+int heat_cf_sync_apply(heat_cf_engine* e, void* d_ref, const void* d_sum, const void* d_mine, float scale);
 /* blocks until everything queued on the engine's stream has finished */
 int heat_cf_synchronize(heat_cf_engine* e);
 

@@ -35,6 +35,7 @@ class OracleWindows:
 
 def main():
     out_dir, mode, window = sys.argv[1], sys.argv[2], int(sys.argv[3])
+    overlap = len(sys.argv) > 4 and sys.argv[4] == "overlap"
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     data = np.load(os.path.join(out_dir, "problem.npz"))
@@ -48,7 +49,7 @@ def main():
 
     agg = dict(his=data["his"], masks=data["masks"], w0=data["w0"]) if "w0" in data.files else {}
     tr = ShardedTrainer(clicks, data["uw"], data["iw"], num_negs=N, sync_interactions=window, mode=mode,
-                        engine_factory=oracle_factory, **agg)
+                        engine_factory=oracle_factory, overlap=overlap, **agg)
     for _ in range(int(data["epochs"])):
         tr.train_one_epoch()
     uw, iw = tr.weights()

@@ -72,11 +72,11 @@ def free_port():
         return s.getsockname()[1]
 
 
-def run_world(tmp_path, mode, window, world=2):
+def run_world(tmp_path, mode, window, world=2, extra=()):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr",
            "127.0.0.1", "--master-port", str(free_port()), os.path.join(ROOT, "tests", "_dist_worker.py"),
-           str(tmp_path), mode, str(window)]
+           str(tmp_path), mode, str(window)] + list(extra)
     res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
     assert res.returncode == 0, res.stdout[-3000:]
     return [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
@@ -166,3 +166,42 @@ def test_aggregator_weights_are_averaged_with_the_item_table(tmp_path):
     assert not np.array_equal(reps_w[0], w0)                               # W0 did move
     np.testing.assert_allclose(ranks[0]["iw"], (reps_i[0] + reps_i[1]) / 2, rtol=0, atol=1e-7)
     np.testing.assert_allclose(ranks[0]["w0"], (reps_w[0] + reps_w[1]) / 2, rtol=0, atol=1e-7)
+
+
+@pytest.mark.timeout(400)
+def test_overlapped_exchange_applies_the_other_ranks_deltas_one_window_late(tmp_path):
+    """overlap=True: the all-reduce of window k is in flight while window k+1 trains; the other rank's delta of window k
+    is added before window k+2 (`W += sum - mine`), the last exchange of the epoch is completed before the epoch ends
+    (bit-identical replicas).  Host-side restatement with three windows per epoch."""
+    clicks, negs, uw, iw, U, N = make_problem(tmp_path, disjoint_items=False, epochs=1)
+    shards = [shard_clicks(clicks, U, 2, r) for r in range(2)]
+    n_max = max(sh.shape[0] for sh, _, _ in shards)
+    window = -(-n_max // 3)
+    ranks = run_world(tmp_path, "sum", window=window, extra=["overlap"])
+    assert np.array_equal(ranks[0]["iw"], ranks[1]["iw"])
+    reps, engs, bases = [], [], []
+    for r, (shard, lo, hi) in enumerate(shards):
+        a = int(np.searchsorted(clicks[:, 0], lo))
+        u, i = uw[lo:hi].copy(), iw.copy()
+        e = orc.Engine(shard, u, i, num_negs=N, l_r=0.01, clip_val=1.0)
+        e.lr_step()
+        reps.append(i); engs.append(e); bases.append(a)
+
+    def train(r, w):
+        n = shards[r][0].shape[0]
+        lo, hi = min(n, w * window), min(n, (w + 1) * window)
+        if hi > lo:
+            engs[r].train_range(lo, hi, negs[bases[r] + lo:bases[r] + hi])
+
+    for r in range(2):
+        train(r, 0)
+    first = [reps[r] - iw for r in range(2)]                 # window-0 deltas, exchanged while window 1 trains
+    for r in range(2):
+        train(r, 1)
+    for r in range(2):
+        reps[r] += first[1 - r]                              # ... and applied before window 2
+    for r in range(2):
+        train(r, 2)
+    ref = iw + first[0] + first[1]
+    want = ref + (reps[0] - ref) + (reps[1] - ref)           # the closing (blocking) exchange
+    np.testing.assert_allclose(ranks[0]["iw"], want, rtol=0, atol=1e-6)

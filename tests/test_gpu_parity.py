@@ -193,6 +193,37 @@ def test_sampler_is_philox_bit_exact():
     eng.close()
 
 
+def test_philox_equals_hiprand_device_api():
+    """north_star names hiprand for the on-GPU sampler.  The kernel hand-rolls Philox4x32-10 so that the generator state
+    stays in registers; oracle/hiprand_kat.hip runs hipRAND's own device API (hiprand_kernel.h: hiprand_init(key, idx,
+    4*slot) + hiprand4) next to the kernel's philox_draw64 on the GPU: the 64-bit draws must be bit-identical, and the ids
+    the product engine reports must be mulhi64(hipRAND draw, num_items)."""
+    import ctypes as C
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "libhiprand_kat.so")
+    assert os.path.exists(path), "oracle/libhiprand_kat.so missing: run __graft_entry__.build() (make -C oracle hiprand)"
+    abi.load()                                                   # one HIP runtime per process (torch's is loaded first)
+    kat = C.CDLL(path)
+    kat.hiprand_kat_draws.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
+    d, N, U, I, T = 64, 100, 20, 90001, 300
+    clicks, uw, iw = small_problem(U, I, T, d, seed=5)
+    for seed, epoch, base in [(2022, 0, 0), (7, 3, 1 << 33)]:
+        key = philox_ref.epoch_key(seed, epoch)
+        a = np.empty((T, N), dtype=np.uint64)
+        b = np.empty((T, N), dtype=np.uint64)
+        assert kat.hiprand_kat_draws(key, base, T, N, a.ctypes.data, b.ctypes.data) == 0
+        assert np.array_equal(a, b)                              # hipRAND device API == the kernel's generator, bit for bit
+        idx = base + np.arange(T, dtype=np.uint64)
+        assert a.ravel().tolist() == philox_ref._draw64(np.tile(np.arange(N, dtype=np.uint32), T), np.repeat(idx, N), key)
+        eng = abi.Engine(clicks, uw, iw, num_negs=N, seed=seed, sample_index_base=base,
+                         flags=abi.FLAG_SERIAL | abi.FLAG_SAMPLING_CALL)   # sampling(): raw draws, no keep-slot rule
+        eng.epoch = epoch
+        got = eng.sample_negatives(0, T)
+        eng.close()
+        want = ((a.astype(object) * I) >> 64).astype(np.uint64)  # mulhi64(draw, num_items) in exact integer arithmetic
+        assert np.array_equal(got, want)
+
+
 def test_sampler_ignore_pos_keeps_previous_slot():
     """3 items: every draw hits the positive with probability 1/3, so the 'slot left unchanged' rule fires often."""
     d, N, T = 64, 16, 640
@@ -587,7 +618,8 @@ def test_randomized_serial_parity_sweep():
     positive collisions included.  Catches variant-specific indexing errors (masked lanes / slots, multi-wave
     workgroups, atomics vs stores)."""
     rng = np.random.default_rng(2024)
-    modes = [abi.UPDATE_OVERWRITE, abi.UPDATE_ATOMIC_W, abi.UPDATE_ATOMIC_WG, abi.UPDATE_ATOMIC_POS, abi.UPDATE_AUTO]
+    modes = [abi.UPDATE_OVERWRITE, abi.UPDATE_ATOMIC_W, abi.UPDATE_ATOMIC_WG, abi.UPDATE_ATOMIC_POS, abi.UPDATE_AUTO,
+             16 + 0x1C, 16 + 0x1E]   # raw bits: late re-read of negative rows (+ positives atomic, + negative G atomic)
     for case in range(40):
         d = int(rng.choice([4, 8, 12, 20, 32, 48, 64, 96, 128, 160, 256]))
         N = int(rng.choice([1, 2, 3, 5, 8, 16, 17, 31, 32, 50, 64, 100]))

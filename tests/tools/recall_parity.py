@@ -25,12 +25,17 @@ ap.add_argument("--clip", type=float, default=1.0)
 ap.add_argument("--seeds", type=str, default="2022")
 ap.add_argument("--clusters", type=int, default=0)
 ap.add_argument("--lr", type=float, default=0.01)
+ap.add_argument("--zipf", type=float, default=1.0, help="item popularity exponent of the synthetic graph")
+ap.add_argument("--in-cluster", type=float, default=0.8)
+ap.add_argument("--oracle-seeds", type=str, default="", help="seeds the oracle runs for (default: every seed)")
 ap.add_argument("--agg", action="store_true", help="behaviour aggregation (ACCL) on both sides")
 ap.add_argument("--tile", action="store_true", help="random-tile negative sampler (neg_sampler 1, tile 512, refresh 8192; the "
                 "`sampling` call, random_tile_negative_sampler.cpp:31-45) on both sides")
 args = ap.parse_args()
 
-g, d, N = synthetic.make_named(args.shape, scale=args.scale, n_clusters=args.clusters)
+g, d, N = synthetic.make_named(args.shape, scale=args.scale, n_clusters=args.clusters, zipf_s=args.zipf, in_cluster=args.in_cluster)
+_pop = np.bincount(g.train_items, minlength=g.num_items)
+print(f"hottest item share of positives {_pop.max() / g.train_items.size:.4f}")
 test_dic = {}
 ep = g.test_indptr.astype(np.int64)
 for u in range(g.num_users):
@@ -75,7 +80,9 @@ for seed in [int(x) for x in args.seeds.split(",")]:
             print(f"GPU seed={seed} coherence={coh} update={upd} {eng.kernel_name} streams={streams}: losses={[round(x, 4) for x in losses]} ({dt:.2f}s)", flush=True)
             eng.close()
             evaluate(uw, iw, f"gpu coh={coh} upd={upd} streams={streams}")
-    for th in [int(x) for x in args.oracle_threads.split(",")]:
+    if args.oracle_seeds and seed not in [int(x) for x in args.oracle_seeds.split(",")]:
+        continue
+    for th in [int(x) for x in args.oracle_threads.split(",") if x]:
         uo, io = uw0.copy(), iw0.copy()
         agg_kw = dict(his=his, masks=masks, w0=w00.copy(), use_aggregator=True) if args.agg else {}
         tile_kw = dict(neg_sampler=1, tile_size=512, refresh_interval=8192) if args.tile else {}
