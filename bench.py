@@ -5,12 +5,19 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-A "step" is one pass (one training epoch: LR step, all interactions, zero_grad) over a seeded synthetic graph of the
-AmazonBooks shape (52 643 users x 91 599 items, 2 380 730 interactions, d=64, 16 uniform negatives drawn on the
-GPU): BASELINE.json configs[1].  With N GPUs every rank owns one such user shard (weak scaling: the job has
-N x 52 643 users), the item table is replicated and synchronised with an RCCL all-reduce (heat_amd.cf.distributed).
-Tables and the interaction list are resident in HBM before the timed region (torch tensors handed to the C ABI as raw
-device pointers).  Rank 0 prints ONE JSON line.
+A "step" is one pass (one training epoch: LR step, all interactions, zero_grad) over ONE seeded synthetic graph of the
+AmazonBooks shape (52 643 users x 91 599 items, 2 380 730 interactions, d=64, 16 uniform negatives drawn on the GPU).
+
+N = 1  : BASELINE.json configs[1].  Tables and the interaction list are resident in HBM before the timed region (torch
+         tensors handed to the C ABI as raw device pointers).  The JSON line also carries the read-only roofline
+         fraction, where the working set lives, a second roofline object from a short HBM-resident run (configs[4]
+         shape, a sample of its interaction list), the same epoch through the reference's own boundary (`cf_c`, host
+         buffers written back every epoch: `value_host_mode`) and the CPU oracle timed on this box's host cores.
+N > 1  : BASELINE.json configs[3]: the SAME graph partitioned by user range (cf/main.py:51-57), one shard per rank, item
+         table replicated, item-table deltas all-reduced over RCCL/xGMI while the next window trains
+         (heat_amd.cf.distributed.ItemSync, overlap).  `value` = the graph's interactions x steps / time: strong scaling.
+         Extra keys: the literal "all-reduce every 8192 steps" window, and a short weak-scaling leg (one graph per rank).
+Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -24,7 +31,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
+INFINITY_CACHE_BYTES = 256 << 20
 
 
 def usable_cpus():
@@ -67,6 +75,118 @@ def cpu_baseline(graph, d, n_negs, threads=8, epochs=6):
                       f"host has {os.cpu_count()} logical CPUs"}
 
 
+def roofline(B, B_rd, interactions, kernel_ms, launches, working_set_bytes, traffic=None, traffic_source=None):
+    """Algorithmic bytes (B = 16 d (N+2) + 16 per interaction; B_rd = the gather half) over the training
+    kernel's HIP-event time, against the HBM peak.  `residency` says where the working set actually lives: a set that
+    fits the 256 MiB Infinity Cache is served from it, and the fraction is then a bandwidth figure quoted against the
+    HBM peak, not DRAM traffic."""
+    per_launch_s = kernel_ms * 1e-3 / max(launches, 1)
+    per_launch = interactions / max(launches, 1)
+    achieved = B * per_launch / per_launch_s / 1e9
+    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "read_frac": B_rd * per_launch / per_launch_s / 1e9 / HBM_PEAK_GBS,
+            "traffic": traffic, "traffic_unit": "GB per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)", "traffic_source": traffic_source,
+            "residency": "infinity-cache" if working_set_bytes <= INFINITY_CACHE_BYTES else "hbm",
+            "working_set_mb": working_set_bytes / 1e6,
+            "algorithmic_gb_per_launch": B * per_launch / 1e9, "bytes_per_interaction": B,
+            "read_bytes_per_interaction": B_rd, "kernel_ms_per_launch": per_launch_s * 1e3, "launches": launches}
+
+
+def replayed_traffic(name, kernel_name):
+    """HBM-side bytes per launch from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same command
+    (tools/pmc_traffic.py: counters cannot be collected from inside the process being timed) — replayed, and labelled so."""
+    path = os.path.join(ROOT, "profiles", name)
+    if not os.path.exists(path):
+        return None, None
+    with open(path) as f:
+        pmc = json.load(f)
+    if not kernel_name.startswith(pmc.get("kernel", "?").rstrip(">")):
+        return None, None
+    return pmc["traffic_bytes_per_launch"] / 1e9, "replayed:profiles/" + name
+
+
+def hbm_resident_leg(dev, stream, interactions, steps=2):
+    """BASELINE.json configs[4] shape (10 M users x 1 M items, d=256, negs=100: 22.5 GB of tables, HBM-resident) on a
+    sample of its 200 M-interaction list; returns a roofline object for the same kernel family."""
+    import torch
+    from heat_amd import abi
+    from heat_amd.cf import synthetic
+    U, I, _, d, N = synthetic.SHAPES["synthetic_hbm"]
+    T = interactions
+    clicks = synthetic.make_clicks_torch(U, I, T, dev, seed=2022)
+    g = torch.Generator(device=dev)
+    g.manual_seed(2022)
+    user_w = torch.empty((U, d), device=dev, dtype=torch.float32).normal_(0.0, 0.01, generator=g)
+    item_w = torch.empty((I, d), device=dev, dtype=torch.float32).normal_(0.0, 0.01, generator=g)
+    eng = abi.Engine.from_device(clicks.data_ptr(), T, user_w.data_ptr(), item_w.data_ptr(), num_users=U, num_items=I,
+                                 emb_dim=d, num_negs=N, stream=stream, keep=(clicks, user_w, item_w), seed=2022)
+    for k in range(1 + steps):
+        if k == 1:
+            torch.cuda.synchronize()
+            eng.kernel_time(reset=True)
+            t0 = time.perf_counter()
+        eng.begin_epoch()
+        eng.train_range(0, T, want_loss=False)
+        eng.end_epoch()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    kernel_ms, launches = eng.kernel_time()
+    B, B_rd = 16 * d * (N + 2) + 16, 8 * d * (N + 2) + 16
+    traffic, src = replayed_traffic("r02_pmc_traffic_hbm.json", eng.kernel_name)
+    out = roofline(B, B_rd, T * steps, kernel_ms, launches, 2 * (U + I) * d * 4, traffic, src)
+    out["workload"] = (f"synthetic 10M x 1M, d={d}, negs={N}: {T} interactions per launch, a sample of the 200M list "
+                       f"(a full pass is 83.6 TB of algorithmic traffic)")
+    out["kernel"] = eng.kernel_name
+    out["samples_per_s"] = T * steps / dt
+    eng.close()
+    del clicks, user_w, item_w
+    torch.cuda.empty_cache()
+    return out
+
+
+class stdout_to_stderr:
+    """cf_c mirrors the reference's constructor print (cf_config.hpp:19); rank 0's stdout must stay ONE JSON line."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+
+
+def host_mode_leg(graph, d, N, steps, pinned):
+    """The same epoch through the reference's own boundary: `cf_c` objects on host numpy buffers, trained in place and
+    written back after every epoch (init_modules.cpp:79-81 contract).  pinned=True: the weight arrays live in page-locked
+    memory (what heat_amd.cf.frontend allocates), so the write-back is one DMA at PCIe rate."""
+    import torch
+    from heat_amd import cf_c
+    from heat_amd.cf import synthetic
+    U, I, T = graph.num_users, graph.num_items, graph.clicks.shape[0]
+    uw, iw = synthetic.init_embeddings(U, I, d, seed=2022)
+    if pinned:
+        keep = (torch.from_numpy(uw).pin_memory(), torch.from_numpy(iw).pin_memory())
+        uw, iw = keep[0].numpy(), keep[1].numpy()
+    cfg = cf_c.modules.CFConfig(emb_dim=d, num_negs=N, num_users=U, num_items=I, train_size=T, neg_sampler=0, tile_size=512,
+                                refresh_interval=8192, num_subepoches=2, l2=1e-7, clip_val=1.0, milestones=[10], l_r=0.01)
+    his = np.zeros((U, 1), dtype=np.uint64)
+    masks = np.zeros((U, 1), dtype=np.uint64)
+    ds = cf_c.modules.datasets.ClickDataset(click_dataset=graph.clicks, historical_items=his, masks=masks)
+    model = cf_c.modules.models.MatrixFactorization(cf_config=cfg, user_weights=uw, item_weights=iw)
+    w0 = np.zeros((d, d), dtype=np.float32)
+    agg = cf_c.modules.behavior_aggregators.AggregatorWeights(aggregator_weights0=w0)
+    eng = cf_c.modules.train.Engine(dataset=ds, aggregator_weights=agg, model=model, cf_config=cfg)
+    eng.train_one_epoch()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        eng.train_one_epoch()
+    dt = time.perf_counter() - t0
+    return T * steps / dt
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -74,9 +194,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--shape", default="amazonbooks")
     ap.add_argument("--update-mode", type=int, default=0, help="HEAT_CF_UPDATE_* (0 = engine default: AUTO)")
-    ap.add_argument("--sync-interactions", type=int, default=0,
-                    help="interactions per GPU between item-table all-reduces (0 = streams x refresh_interval, see DESIGN.md)")
+    ap.add_argument("--num-streams", type=int, default=0)
+    ap.add_argument("--windows", type=int, default=0, help="N>1: item-table exchanges per epoch (0 = default, see DESIGN.md section 5)")
+    ap.add_argument("--no-overlap", action="store_true", help="N>1: complete every exchange before the next window")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the HBM-resident, host-mode, literal-window and weak-scaling legs")
     ap.add_argument("--interactions", type=int, default=0,
                     help="interactions per step for --shape synthetic_hbm (0 = 20 000 000: a sample of the 200 M list)")
     args = ap.parse_args()
@@ -85,6 +207,7 @@ def main():
     import torch.distributed as dist
     from heat_amd import abi
     from heat_amd.cf import synthetic
+    from heat_amd.cf.distributed import ItemSync, shard_bounds, shard_clicks
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -108,110 +231,163 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    # one side stream carries everything: engine kernels, the torch element-wise ops of the item sync and (through
-    # torch.distributed's stream hand-off) the RCCL all-reduce are ordered with respect to each other
+    # one side stream carries the engine kernels and the fused delta / apply passes of the item exchange; the RCCL
+    # all-reduce runs on torch.distributed's own stream, ordered against this one by events (async collective)
     side = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(side)
-    U, I, T, d, N = synthetic.SHAPES[args.shape]
-    graph = None
-    if args.shape == "synthetic_hbm":
-        # BASELINE.json configs[4]: 10 M users x 1 M items, d=256, negs=100 (tables 22.5 GB: the true HBM-resident run).
-        # A step walks a 20 M-interaction sample of the 200 M list (a full pass is 83.6 TB of algorithmic traffic).
-        T = args.interactions or 20_000_000
-        clicks = synthetic.make_clicks_torch(U, I, T, dev, seed=2022 + rank)
-        g = torch.Generator(device=dev)
-        g.manual_seed(2022)
-        user_w = torch.empty((U, d), device=dev, dtype=torch.float32).normal_(0.0, 0.01, generator=g)
-        item_w = torch.empty((I, d), device=dev, dtype=torch.float32).normal_(0.0, 0.01, generator=g)
-        args.no_cpu_baseline = True
-    else:
-        # every rank generates its own shard (different seed = different users), same item id space
-        graph = synthetic.make_graph(U, I, T, seed=2022 + rank, with_test=False)
-        uw_h, iw_h = synthetic.init_embeddings(U, I, d, seed=2022)
-        clicks = torch.from_numpy(graph.clicks.view(np.int64)).to(dev)
-        user_w = torch.from_numpy(uw_h).to(dev)
-        item_w = torch.from_numpy(iw_h).to(dev)       # identical on every rank (replicated table)
     stream = torch.cuda.current_stream().cuda_stream
-    eng = abi.Engine.from_device(clicks.data_ptr(), T, user_w.data_ptr(), item_w.data_ptr(), num_users=U, num_items=I,
-                                 emb_dim=d, num_negs=N, stream=stream, keep=(clicks, user_w, item_w), seed=2022,
-                                 sample_index_base=rank * T, update_mode=args.update_mode, device=local_rank)
-    trainer = None
-    if world > 1 or os.environ.get("HEAT_BENCH_FORCE_SYNC"):   # the env switch exercises the N>1 code path on one GPU
-        from heat_amd.cf.distributed import ItemSync
-        trainer = ItemSync(eng, item_w, world, refresh_interval=8192, sync_interactions=args.sync_interactions)
+    U, I, T, d, N = synthetic.SHAPES[args.shape]
+    B, B_rd = 16 * d * (N + 2) + 16, 8 * d * (N + 2) + 16          # algorithmic bytes per interaction
+    force_sync = bool(os.environ.get("HEAT_BENCH_FORCE_SYNC"))     # exercises the N>1 exchange path on one GPU
+    graph = None
 
-    def step():
-        if trainer is None:
-            eng.begin_epoch()
-            eng.train_range(0, T, want_loss=False)
-            eng.end_epoch()
-        else:
-            trainer.train_one_epoch()
+    def build(clicks_np, n_users, user_rows, base, seed_graph_note):
+        clicks = torch.from_numpy(clicks_np.view(np.int64)).to(dev)
+        user_w = torch.from_numpy(np.ascontiguousarray(user_rows)).to(dev)
+        item_w = torch.from_numpy(iw_h).to(dev)                   # identical on every rank (replicated table)
+        eng = abi.Engine.from_device(clicks.data_ptr(), clicks_np.shape[0], user_w.data_ptr(), item_w.data_ptr(),
+                                     num_users=n_users, num_items=I, emb_dim=d, num_negs=N, stream=stream,
+                                     keep=(clicks, user_w, item_w), seed=2022, sample_index_base=base,
+                                     update_mode=args.update_mode, num_streams=args.num_streams, device=local_rank)
+        return eng, item_w
 
     def fence():
         if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed(step, steps, warmup, finish=None):
+        for _ in range(warmup):
+            step()
+        if finish:
+            finish()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        if finish:
+            finish()
+        fence()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return elapsed
+
+    extra = {}
+    if args.shape == "synthetic_hbm":
+        # BASELINE.json configs[4] as the main workload (profiling runs): every rank its own sample of the list
+        T = args.interactions or 20_000_000
+        clicks = synthetic.make_clicks_torch(U, I, T, dev, seed=2022 + rank)
+        g = torch.Generator(device=dev)
+        g.manual_seed(2022)
+        user_w = torch.empty((U, d), device=dev, dtype=torch.float32).normal_(0.0, 0.01, generator=g)
+        item_w = torch.empty((I, d), device=dev, dtype=torch.float32).normal_(0.0, 0.01, generator=g)
+        eng = abi.Engine.from_device(clicks.data_ptr(), T, user_w.data_ptr(), item_w.data_ptr(), num_users=U, num_items=I,
+                                     emb_dim=d, num_negs=N, stream=stream, keep=(clicks, user_w, item_w), seed=2022,
+                                     sample_index_base=rank * T, update_mode=args.update_mode,
+                                     num_streams=args.num_streams, device=local_rank)
+        args.no_cpu_baseline = args.no_extra_legs = True
+        my_T, total_T, scaling = T, world * T, "weak"
+        workload = (f"synthetic 10M x 1M shape per GPU: {U} users x {I} items, d={d}, negs={N}, {T} interactions per step "
+                    f"(a sample of the 200 M list), uniform on-GPU Philox sampler")
+        working_set = 2 * (U + I) * d * 4
+        trainer = None
+    else:
+        graph = synthetic.make_graph(U, I, T, seed=2022, with_test=False)       # ONE graph, the same on every rank
+        uw_h, iw_h = synthetic.init_embeddings(U, I, d, seed=2022)
+        lo, hi = shard_bounds(U, world, rank)                                   # cf/main.py:51-57 (rank 0 fixed)
+        shard, lo, hi = shard_clicks(graph.clicks, U, world, rank, bounds=(lo, hi))
+        base = int(np.searchsorted(graph.clicks[:, 0], lo, side="left"))
+        eng, item_w = build(shard, hi - lo, uw_h[lo:hi], base, None)
+        my_T, total_T, scaling = shard.shape[0], T, ("strong" if world > 1 else "weak")
+        workload = (f"{args.shape}-shaped synthetic graph: {U} users x {I} items, {T} interactions, d={d}, negs={N}, uniform "
+                    f"on-GPU Philox sampler; 1 step = 1 epoch" +
+                    (f"; user rows partitioned over {world} GPUs (cf/main.py:51-57), item table replicated" if world > 1 else ""))
+        working_set = 2 * ((hi - lo) + I) * d * 4
+        trainer = None
+        if world > 1 or force_sync:
+            # default exchange schedule: 2 windows per epoch, every all-reduce overlapped with the next window (also across
+            # the epoch boundary); the pipeline is drained inside the timed region
+            trainer = ItemSync(eng, item_w, world, windows_per_epoch=args.windows or 2, mode="sum",
+                               force_collective=force_sync, overlap=not args.no_overlap, defer_final=not args.no_overlap)
+
+    def step():
+        if trainer is None:
+            eng.begin_epoch()
+            eng.train_range(0, my_T, want_loss=False)
+            eng.end_epoch()
+        else:
+            trainer.train_one_epoch()
+
+    finish = trainer.finalize if trainer is not None else None
     for _ in range(args.warmup):
         step()
+    if finish:
+        finish()
     fence()
     eng.kernel_time(reset=True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = timed(step, args.steps, 0, finish)
     kernel_ms, launches = eng.kernel_time()
 
-    traffic = None
-    pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if os.path.exists(pmc_path) and args.shape == "amazonbooks" and args.update_mode == 0:
-        # HBM bytes per launch from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same command
-        # (tools/pmc_traffic.py; counters cannot be collected from inside the process being timed)
-        with open(pmc_path) as f:
-            pmc = json.load(f)
-        if eng.kernel_name.startswith(pmc.get("kernel", "?").rstrip(">")):
-            traffic = pmc["traffic_bytes_per_launch"] / 1e9
+    if world > 1 and not args.no_extra_legs and trainer is not None:
+        # (a) the literal reading of configs[3]: one all-reduce every 8192 interactions per GPU
+        lit = ItemSync(eng, item_w, world, sync_interactions=8192, mode="sum", overlap=not args.no_overlap,
+                       defer_final=not args.no_overlap)
+        k = max(1, min(3, args.steps))
+        el = timed(lit.train_one_epoch, k, 1, lit.finalize)
+        extra["item_sync_every_8192"] = {"value": T * k / el, "unit": "samples/s", "ms_per_step": el / k * 1e3, "steps": k,
+                                         "item_sync": lit.describe(), "exchanges_per_epoch_per_gpu": -(-(T // world) // 8192)}
+        # (b) weak scaling: every rank its own AmazonBooks-shaped graph (different users, same item space)
+        g2 = synthetic.make_graph(U, I, T, seed=2022 + 1000 * (rank + 1), with_test=False)
+        eng2, item2 = build(g2.clicks, U, uw_h, (rank + 1) * T, None)
+        tr2 = ItemSync(eng2, item2, world, windows_per_epoch=args.windows or 2, mode="sum", overlap=not args.no_overlap,
+                       defer_final=not args.no_overlap)
+        k = max(1, min(5, args.steps))
+        el = timed(tr2.train_one_epoch, k, 1, tr2.finalize)
+        extra["weak_scaling"] = {"value": world * T * k / el, "unit": "samples/s", "ms_per_step": el / k * 1e3, "steps": k,
+                                 "workload": f"one {args.shape}-shaped graph PER GPU ({world} x {T} interactions per step)",
+                                 "item_sync": tr2.describe()}
+        eng2.close()
 
     if rank == 0:
-        total = world * T * args.steps
-        B = 16 * d * (N + 2) + 16                 # algorithmic bytes per interaction
-        per_launch_s = kernel_ms * 1e-3 / max(launches, 1)
-        inter_per_launch = T * args.steps / max(launches, 1)
-        achieved = B * inter_per_launch / per_launch_s / 1e9
+        traffic, traffic_src = (None, None)
+        if world == 1 and args.shape == "amazonbooks" and args.update_mode == 0 and args.num_streams == 0:
+            traffic, traffic_src = replayed_traffic("r02_pmc_traffic.json", eng.kernel_name)
         out = {
             "metric": "positive-samples/sec/node (AmazonBooks d=64, negs=16)" if args.shape == "amazonbooks"
             else f"positive-samples/sec/node ({args.shape} d={d}, negs={N})",
-            "value": total / elapsed,
+            "value": total_T * args.steps / elapsed,
             "unit": "samples/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"{args.shape}-shaped synthetic graph per GPU: {U} users x {I} items, {T} interactions, "
-                                   f"d={d}, negs={N}, uniform on-GPU Philox sampler; 1 step = 1 epoch",
-                       "kernel": eng.kernel_name,
+            "config": {"workload": workload, "kernel": eng.kernel_name,
                        "item_sync": None if trainer is None else trainer.describe()},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "GB per launch (PMC)",
-                         "algorithmic_gb_per_launch": B * inter_per_launch / 1e9,
-                         "bytes_per_interaction": B, "kernel_ms_per_launch": per_launch_s * 1e3,
-                         "launches": launches},
+            # rank 0's training kernel: its shard's interactions over its HIP-event time
+            "roofline": roofline(B, B_rd, my_T * args.steps, kernel_ms, launches, working_set, traffic, traffic_src),
         }
+        out.update(extra)
+        if world == 1 and not args.no_extra_legs:
+            k = max(2, min(10, args.steps))
+            with stdout_to_stderr():
+                out["value_host_mode"] = host_mode_leg(graph, d, N, k, pinned=True)
+                out["value_host_mode_pageable"] = host_mode_leg(graph, d, N, k, pinned=False)
+            out["host_mode_note"] = ("same epoch through cf_c on host numpy buffers, weights written back after every epoch "
+                                     "(PCIe-inclusive; never `value`): page-locked arrays as heat_amd.cf.frontend allocates "
+                                     "them / plain pageable numpy arrays")
+            out["roofline_hbm_resident"] = hbm_resident_leg(dev, stream, 4_000_000)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(graph, d, N)
             ncpu = usable_cpus()
-            if ncpu > 8:   # SURVEY §8d: also at all the cores this process may use
+            if ncpu > 8:   # SURVEY 8d: also at all the cores this process may use
                 out["cpu_baseline_all_cores"] = cpu_baseline(graph, d, N, threads=ncpu, epochs=4)
         print(json.dumps(out), flush=True)
     if dist.is_initialized():

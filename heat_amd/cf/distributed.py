@@ -72,7 +72,8 @@ class ItemSync:
     the table)."""
 
     def __init__(self, engine, item_w, world_size, refresh_interval=8192, sync_interactions=0, mode="sum", streams=0,
-                 force_collective=False, mean_tensors=(), negatives=None, overlap=False, defer_final=False, dist=None):
+                 force_collective=False, mean_tensors=(), negatives=None, overlap=False, defer_final=False, dist=None,
+                 windows_per_epoch=0):
         if dist is None:
             import torch.distributed as dist
         self.dist = dist
@@ -86,6 +87,7 @@ class ItemSync:
             streams = streams or getattr(engine, "num_streams", 0) or 3022
             sync_interactions = streams * refresh_interval
         self.window = max(1, int(sync_interactions))   # clamped to the LARGEST shard inside train_one_epoch (same on every rank)
+        self.windows_per_epoch = int(windows_per_epoch)   # > 0: the largest shard is cut into this many equal windows instead
         self.force = bool(force_collective)     # run the collective path even with one rank (tests)
         if mode not in ("sum", "mean"):
             raise ValueError("mode must be 'sum' or 'mean'")
@@ -105,7 +107,8 @@ class ItemSync:
     def describe(self):
         return {"collective": "all_reduce(item table delta)" + (" + all_reduce(W0)" if self.mean_tensors else ""), "mode": self.mode,
                 "overlap": self.overlap, "fused_delta_apply_kernels": bool(self.native),
-                "window_interactions_per_gpu": min(self.window, self.engine.data_rows)}
+                "window_interactions_per_gpu": getattr(self, "last_window", min(self.window, self.engine.data_rows)),
+                "exchanges": self.exchanges}
 
     # ---- the two element-wise passes --------------------------------------------------------------------------------
     def _delta(self, with_mine):
@@ -179,7 +182,10 @@ class ItemSync:
                 self._n_max = n
         n_max = self._n_max
         window = min(self.window, max(1, n_max))
+        if self.windows_per_epoch > 0:
+            window = max(1, -(-n_max // self.windows_per_epoch))
         n_windows = max(1, -(-n_max // window))
+        self.last_window = window
         e.begin_epoch()
         loss_sum = 0.0
         for w in range(n_windows):

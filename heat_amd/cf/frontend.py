@@ -78,7 +78,13 @@ class MatrixFactorization(Model):
     _c_path = "modules.models.MatrixFactorization"
 
     def init_c_instance(self, config=None):
-        # numpy views of the torch parameters: the engine trains them in place (models.py:30-32)
+        # numpy views of the torch parameters: the engine trains them in place (models.py:30-32).  Where a GPU is present
+        # the parameters are moved to page-locked host memory first: the engine's per-epoch write-back into these very
+        # buffers (the reference's in-place contract, init_modules.cpp:79-81) is then one DMA at PCIe rate instead of a
+        # staged pageable copy.
+        if torch.cuda.is_available():
+            for table in (self.user_embedding, self.item_embedding):
+                table.weight.data = table.weight.data.pin_memory()
         self.user_weights = self.user_embedding.weight.detach().cpu().numpy()
         self.item_weights = self.item_embedding.weight.detach().cpu().numpy()
         CPPBase.init_c_instance(self, cf_config=config.c_instance, user_weights=self.user_weights,

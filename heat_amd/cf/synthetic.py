@@ -12,7 +12,8 @@ import numpy as np
 # name -> (num_users, num_items, train interactions, emb_dim, num_negs)   (README.md:77-79; paper §5.1; BASELINE.json)
 SHAPES = {
     "amazonbooks": (52643, 91599, 2380730, 64, 16),
-    "gowalla": (29858, 40981, 810128, 64, 16),
+    "gowalla": (29858, 40981, 810128, 128, 64),      # this fork's Gowalla/MF_CCL/configs/config0.yaml:9-11 (d=128, 64 negatives)
+    "gowalla_pr1": (29858, 40981, 810128, 64, 16),   # BASELINE.json configs[0] ("PR1": d=64, 16 negatives; config_pr1.yaml)
     "yelp18": (31668, 38048, 1237259, 128, 64),
     "synthetic_hbm": (10_000_000, 1_000_000, 200_000_000, 256, 100),
 }

@@ -234,7 +234,9 @@ __global__ __launch_bounds__(64 * NW) void ccl_train_kernel(TrainArgs a)
     // how many groups ahead the G rows are fetched in the backward sweep: a short look-ahead keeps the read-modify-write
     // window of a negative's G row small (fewer Hogwild collisions) where rows are small and hot; the multi-wave
     // variants (large rows, large tables) fetch deep to cover HBM latency
-    constexpr int GPF = NW > 1 ? (NGW < 16 ? NGW : 16) : (NGW < 4 ? NGW : 4);
+    // RR (late re-read): the point is the SHORT window, so W and G of a group are requested only two groups ahead of its
+    // update and not before the softmax statistics are known
+    constexpr int GPF = RR ? (NGW < 2 ? NGW : 2) : (NW > 1 ? (NGW < 16 ? NGW : 16) : (NGW < 4 ? NGW : 4));
     const int lane = (int)(threadIdx.x & 63u);
     const int wave = NW == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t wave_base = (uint32_t)(wave * WCAP);
@@ -590,11 +592,10 @@ __global__ __launch_bounds__(64 * NW) void ccl_train_kernel(TrainArgs a)
             // GPF groups ahead of their use in the backward sweep
             f32x4 gpf[GPF];                                             // G rows in flight
             f32x4 wpf[RR ? GPF : 1];                                    // late re-read of the W rows (RR)
-#pragma unroll
-            for (int g = 0; g < GPF && g < NGW; ++g)
+            if (!RR)
             {
-                gpf[g] = buf_load<AUX>(item_g, noff[g]);
-                if (RR) wpf[g] = buf_load<AUX>(item_w, noff[g]);
+#pragma unroll
+                for (int g = 0; g < GPF && g < NGW; ++g) gpf[g] = buf_load<AUX>(item_g, noff[g]);
             }
             mx = cross_max<LPR>(mx);                                    // maximum over this wave's slots
             float ssum = 0.0f;
@@ -643,6 +644,16 @@ __global__ __launch_bounds__(64 * NW) void ccl_train_kernel(TrainArgs a)
             const f32x4 upp = -(pp * u4 - up * p4) * r_u_p3;
             f32x4 gu_acc = {0, 0, 0, 0};
             float slg = 0.0f;
+            if (RR)
+            {
+                __builtin_amdgcn_sched_barrier(0);                      // not hoisted above the softmax exchange
+#pragma unroll
+                for (int g = 0; g < GPF && g < NGW; ++g)
+                {
+                    gpf[g] = buf_load<AUX>(item_g, noff[g]);
+                    wpf[RR ? g : 0] = buf_load<AUX>(item_w, noff[g]);
+                }
+            }
 #pragma unroll
             for (int g = 0; g < NGW; ++g)
             {
@@ -945,12 +956,13 @@ bool pick_variant(uint32_t emb_dim, uint32_t num_negs, bool single_wave, int* lp
         }
     }
     int best_cap = 0, best_g = 0, best_w = 0;
-    // smallest capacity that fits; among equals the fewest register groups per wave (= most waves per workgroup):
-    // measured at Yelp18 shape <32,8,4> 0.81 > <32,16,2> 0.78 > <32,32,1> 0.74 of HBM peak (profiles/r01_variant_sweep.txt);
+    // smallest capacity that fits; among equals the fewest register groups per wave, down to 4 (= most waves per workgroup):
+    // measured at Yelp18 shape with 256 streams <32,4,8> 31.1 ms > <32,2,16> 37.2 = <32,8,4> 37.4 ms per epoch
+    // (profiles/r02_yelp18_policy_sweep.txt); uncapped, round 1: <32,8,4> 0.81 > <32,16,2> 0.78 > <32,32,1> 0.74 of HBM peak;
     // splitting a small interaction (<= 4 groups) over two waves is slower (<16,2,2> 0.75 vs <16,4,1> 0.85)
 #define X(L, G, W)                                                                                   \
     if (L == lpr && (uint32_t)(G * R * W) >= num_negs && (!single_wave || W == 1) &&                   \
-        (best_cap == 0 || G * R * W < best_cap || (G * R * W == best_cap && G < best_g && G >= 8)))    \
+        (best_cap == 0 || G * R * W < best_cap || (G * R * W == best_cap && G < best_g && G >= 4)))    \
     {                                                                                                  \
         best_cap = G * R * W;                                                                          \
         best_g = G;                                                                                    \

@@ -133,27 +133,37 @@ struct Plan
 
 // fill = workgroups the chip can keep resident for the chosen variant (from the occupancy query; 0 = unknown: caps only)
 // history_rows = rows an interaction reads besides user / positive / negatives (max_his with behaviour aggregation)
-int make_plan(const heat_cf_config* cfg, uint64_t data_rows, uint64_t fill, Plan* p, uint64_t history_rows = 0)
+// cus = compute units of the device (256 on MI355X)
+int make_plan(const heat_cf_config* cfg, uint64_t data_rows, uint64_t fill, Plan* p, uint64_t history_rows = 0, uint32_t cus = 256)
 {
     int rc = validate_cfg(cfg, data_rows, &p->lpr, &p->ng, &p->nw);
     if (rc) return rc;
     const uint32_t coh = cfg->coherence == HEAT_CF_COHERENCE_DEFAULT ? HEAT_CF_COHERENCE_DEVICE : cfg->coherence;
     if (coh != HEAT_CF_COHERENCE_PLAIN && coh != HEAT_CF_COHERENCE_DEVICE) return fail(HEAT_CF_EINVAL, "bad coherence");
     p->coherence = coh;
-    // streams: enough sequential walkers to fill the chip, but never more asynchrony than was validated against the
-    // oracle at AmazonBooks shape: 3072 streams x 17 item rows in flight over 91 599 item rows = 0.56 in-flight touches
-    // per item row (and 5.8 % of the users in flight).  What an interaction suffers is the number of ITS rows another
-    // stream changes while it is in flight, in-flight touches x (num_negs + 1): measured epoch-loss lag against the
-    // oracle grows with that product (Yelp18 shape, 65 rows: +9 % at 0.56, +3 % at 0.15;
-    // profiles/r01_recall_parity_yelp18_yaml_clip.txt), so above 17 rows per interaction the bound shrinks with it.
-    // Behaviour aggregation also reads up to max_his history rows whose staleness enters the same way (AmazonBooks shape,
-    // profiles/r01_recall_parity_accl_streams2.txt: Recall@20 within 1e-3 of the oracle up to 640 streams, -2e-3 at 1024).
+    // Streams = interactions in flight.  Every one of them computes its gradient from rows that the others are changing,
+    // so their number is bounded by what was validated against the oracle's Recall@20 / NDCG@20 (+-1e-3), expressed as
+    // in-flight touches per item row, streams x (num_negs + 1) / num_items:
+    //   * <= 17 rows per interaction (AmazonBooks / Gowalla-PR1 configs): 0.56 (3017 streams at AmazonBooks shape) with
+    //     positives written back by float atomics and negatives by plain stores;
+    //   * more rows per interaction (Yelp18 config: 65): 0.45 (256 streams at Yelp18 shape, clustered graph, three seeds;
+    //     400 streams = 0.68 is at the edge) — and only with the "late re-read" write-back of the negative rows; with
+    //     the plain store (read-modify-write window = the whole interaction) the same shape holds the tolerance only up
+    //     to 0.15 (85 streams; profiles/r02_yelp18_policy_sweep.txt);
+    //   * behaviour aggregation reads up to max_his history rows whose staleness enters the same way; its bound is the
+    //     round-1 one (AmazonBooks shape: Recall@20 within 1e-3 of the oracle up to 640 streams, -2e-3 at 1024).
     const double rows_per_interaction = (double)(cfg->num_negs + 1);
-    const double in_flight = 0.56 * std::min(1.0, 17.0 / (rows_per_interaction + (double)history_rows));
+    const bool wide = rows_per_interaction > 17.0;
+    const bool can_reread = wide && !cfg->use_aggregator && coh == HEAT_CF_COHERENCE_DEVICE;
+    double in_flight = 0.56;
+    if (cfg->use_aggregator) in_flight = 0.56 * std::min(1.0, 17.0 / (rows_per_interaction + (double)history_rows));
+    else if (wide) in_flight = can_reread ? 0.45 : 0.15;
     p->cap_items = (uint32_t)std::min<uint64_t>(0xFFFFFFFFull, (uint64_t)(in_flight * (double)cfg->num_items / rows_per_interaction));
     p->cap_users = (uint32_t)std::min<uint64_t>(0xFFFFFFFFull, (uint64_t)(0.058 * (double)cfg->num_users));
     uint64_t streams = std::min<uint64_t>(p->cap_items, p->cap_users);
     if (fill) streams = std::min(streams, fill);
+    // a few workgroups more than a whole number per compute unit would make those units the tail of the launch
+    if (cus && streams > cus && streams < 4ull * cus) streams -= streams % cus;
     if (streams < 1) streams = 1;
     if (cfg->num_streams) streams = cfg->num_streams;
     if (cfg->flags & HEAT_CF_FLAG_SERIAL) streams = 1;
@@ -163,18 +173,22 @@ int make_plan(const heat_cf_config* cfg, uint64_t data_rows, uint64_t fill, Plan
     if (coh != HEAT_CF_COHERENCE_DEVICE && um == HEAT_CF_UPDATE_AUTO) um = HEAT_CF_UPDATE_OVERWRITE;
     if (um == HEAT_CF_UPDATE_AUTO)
     {
-        const double touches = (double)streams * (double)cfg->num_negs / (double)cfg->num_items;
-        um = touches <= 0.56 ? HEAT_CF_UPDATE_ATOMIC_POS : HEAT_CF_UPDATE_ATOMIC_WG;
+        const double touches = (double)streams * rows_per_interaction / (double)cfg->num_items;
+        if (cfg->use_aggregator || !wide) um = touches <= 0.6 ? HEAT_CF_UPDATE_ATOMIC_POS : HEAT_CF_UPDATE_ATOMIC_WG;
+        else if (touches <= 0.15) um = HEAT_CF_UPDATE_ATOMIC_POS;
+        else um = can_reread ? HEAT_CF_UPDATE_REREAD_POS : HEAT_CF_UPDATE_ATOMIC_WG;
     }
     uint32_t bits;
     if (um == HEAT_CF_UPDATE_OVERWRITE) bits = 0u;
     else if (um == HEAT_CF_UPDATE_ATOMIC_W) bits = 0x5u;
     else if (um == HEAT_CF_UPDATE_ATOMIC_WG) bits = 0xFu;
     else if (um == HEAT_CF_UPDATE_ATOMIC_POS) bits = 0xCu;
+    else if (um == HEAT_CF_UPDATE_REREAD_POS) bits = 0x1Cu;
     else if (um >= 16u && um < 48u) bits = um - 16u;
     else return fail(HEAT_CF_EINVAL, "bad update_mode");
     if (bits != 0u && coh != HEAT_CF_COHERENCE_DEVICE)
-        return fail(HEAT_CF_EINVAL, "atomic update modes need HEAT_CF_COHERENCE_DEVICE");
+        return fail(HEAT_CF_EINVAL, "atomic / re-read update modes need HEAT_CF_COHERENCE_DEVICE");
+    if ((bits & 0x10u) && cfg->use_aggregator) return fail(HEAT_CF_EUNSUP, "the late re-read write-back is not built for behaviour aggregation");
     p->update_mode = um;
     p->upd_bits = bits;
     return HEAT_CF_OK;
@@ -224,7 +238,7 @@ int common_init(heat_cf_engine* e, const heat_cf_config* cfg, uint64_t data_rows
     // resident workgroups per CU as the runtime reports them for this variant (register / LDS limited)
     int per_cu = query_blocks_per_cu(e->lpr, e->ng, e->nw, e->aux, cfg->use_aggregator != 0, (uint32_t)cfg->emb_dim);
     if (per_cu < 1) per_cu = 1;
-    prc = make_plan(cfg, data_rows, (uint64_t)e->cu_count * (uint64_t)per_cu, &plan, history_rows);
+    prc = make_plan(cfg, data_rows, (uint64_t)e->cu_count * (uint64_t)per_cu, &plan, history_rows, e->cu_count);
     if (prc) return prc;
     e->auto_streams = plan.streams;
     e->upd = (int)plan.upd_bits;
@@ -374,7 +388,8 @@ int heat_cf_plan(const heat_cf_config* cfg, uint64_t data_rows, uint64_t residen
     const char* um = p.update_mode == HEAT_CF_UPDATE_OVERWRITE ? "OVERWRITE"
                    : p.update_mode == HEAT_CF_UPDATE_ATOMIC_W ? "ATOMIC_W"
                    : p.update_mode == HEAT_CF_UPDATE_ATOMIC_WG ? "ATOMIC_WG"
-                   : p.update_mode == HEAT_CF_UPDATE_ATOMIC_POS ? "ATOMIC_POS" : "RAW";
+                   : p.update_mode == HEAT_CF_UPDATE_ATOMIC_POS ? "ATOMIC_POS"
+                   : p.update_mode == HEAT_CF_UPDATE_REREAD_POS ? "REREAD_POS" : "RAW";
     const int n = std::snprintf(out, (size_t)out_bytes,
                                 "{\"lanes_per_row\": %d, \"groups_per_wave\": %d, \"waves_per_workgroup\": %d, "
                                 "\"negative_capacity\": %d, \"coherence\": \"%s\", \"streams\": %u, \"cap_items\": %u, "

@@ -62,9 +62,12 @@ extern "C" {
 #define HEAT_CF_UPDATE_ATOMIC_W   2 /* W by atomic add for every item row, G overwritten                             */
 #define HEAT_CF_UPDATE_ATOMIC_WG  3 /* W and G by atomic add for every item row: no update is ever lost              */
 #define HEAT_CF_UPDATE_ATOMIC_POS 4 /* positive item row: W and G by atomic add; negative rows: overwrite            */
-#define HEAT_CF_UPDATE_AUTO       5 /* ATOMIC_POS while the expected number of concurrent touches of a negative row,
-                                       streams * num_negs / num_items, is <= 0.56 (the regime validated against the
-                                       oracle), ATOMIC_WG otherwise                                                   */
+#define HEAT_CF_UPDATE_AUTO       5 /* up to 17 rows per interaction: ATOMIC_POS (validated up to 0.56 in-flight touches per
+                                       item row, streams * (num_negs + 1) / num_items); more rows per interaction:
+                                       ATOMIC_POS up to 0.15 in-flight touches, REREAD_POS above                      */
+#define HEAT_CF_UPDATE_REREAD_POS 6 /* positive row: W and G by atomic add; negative rows: W re-read together with G two
+                                       row groups ahead of the update, plain stores ("late re-read": the
+                                       read-modify-write window of a negative row is one memory round trip)           */
 /* values 16..47: raw policy bits (16 + bit0 neg W atomic + bit1 neg G atomic + bit2 pos W atomic + bit3 pos G atomic
  *                + bit4 "late re-read": a negative row's W is read again next to its G row just before its update and the
  *                update is applied to that fresh value — the read-modify-write window of a negative row shrinks from
@@ -97,9 +100,10 @@ typedef struct heat_cf_config
     uint32_t coherence;         /* HEAT_CF_COHERENCE_* */
     int32_t  device;            /* HIP device ordinal; -1 = current device */
     uint32_t num_streams;       /* concurrent sequential interaction streams (workgroups); 0 = auto: what fills the GPU,
-                                   capped at 0.56 * num_items / (num_negs + 1) — times 17 / (num_negs + 1) above 17 rows
-                                   per interaction — and 5.8 % of num_users (the asynchrony validated against the
-                                   oracle at AmazonBooks and Yelp18 shape) */
+                                   capped at 0.56 * num_items / (num_negs + 1) (0.45 above 17 rows per interaction) and
+                                   5.8 % of num_users — the asynchrony validated against the oracle's Recall/NDCG at
+                                   AmazonBooks and Yelp18 shape, DESIGN.md section 3 — rounded down to whole workgroups
+                                   per compute unit */
     uint32_t update_mode;       /* HEAT_CF_UPDATE_* */
 } heat_cf_config;
 

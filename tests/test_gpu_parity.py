@@ -337,30 +337,96 @@ def test_recall_ndcg_parity_amazonbooks_shape():
     assert abs(rg[ms[1]] - ro[ms[1]]) <= 1e-3, (rg, ro_runs)
 
 
-def test_epoch_loss_parity_yelp18_shape():
-    """BASELINE.json configs[2] at the Yelp18 yaml's hyper-parameters (d=128, 64 negatives, clip_val 0.1): 65 rows per
-    interaction make the walk more sensitive to asynchrony than the AmazonBooks config, and make_plan bounds the stream
-    count accordingly.  The default engine's mean loss of the first two epochs stays within
-    3 % of the 8-thread oracle's (uncapped, 327 streams, it drifts to +9 % by epoch 8)."""
-    g, d, N = synthetic.make_named("yelp18", with_test=False)
-    assert (d, N) == (128, 64)
-    uw0, iw0 = synthetic.init_embeddings(g.num_users, g.num_items, d, seed=1)
-    uw, iw = uw0.copy(), iw0.copy()
-    eng = abi.Engine(g.clicks, uw, iw, num_negs=N, seed=1, clip_val=0.1, l_r=0.01, flags=abi.FLAG_LAZY_SYNC)
-    assert abi.plan(emb_dim=d, num_negs=N, num_users=g.num_users, num_items=g.num_items, train_size=g.clicks.shape[0])["streams"] == 85
-    got = [eng.train_one_epoch() for _ in range(2)]
-    eng.close()
-    uo, io = uw0.copy(), iw0.copy()
-    ora = orc.Engine(g.clicks, uo, io, num_negs=N, clip_val=0.1, l_r=0.01)
-    want = [ora.train_one_epoch(num_threads=8) for _ in range(2)]
-    for a, b in zip(got, want):
-        assert abs(a - b) <= 0.03 * b, (got, want)
+def _statistical_parity(shape, *, n_clusters, epochs, clip, seeds, lr=0.01):
+    """Hogwild GPU engine (default launch plan, on-GPU Philox negatives) vs the 8-thread oracle (mt19937_64 negatives) on the
+    same synthetic graph and the same N(0, 0.01^2) tables, once per seed.  The two sides draw different negatives and
+    interleave differently, so the comparison is statistical: Recall@20 / NDCG@20 after `epochs` epochs, both sides ranked
+    by the same fused top-k kernel.  Oracle runs for different seeds go through two host threads at a time (the C call
+    releases the GIL) to keep the test short."""
+    import types
+    from concurrent.futures import ThreadPoolExecutor
+    from heat_amd.cf import metrics
+    g, d, N = synthetic.make_named(shape, n_clusters=n_clusters)
+    ep = g.test_indptr.astype(np.int64)
+    test = types.SimpleNamespace(user_items_dic={u: g.test_items[ep[u]:ep[u + 1]].tolist()
+                                                 for u in range(g.num_users) if ep[u + 1] > ep[u]})
+    ms = ["Recall(k=20)", "NDCG(k=20)"]
+
+    def rank_and_score(uw, iw):
+        ev = abi.Engine(g.clicks[:1].copy(), uw, iw, num_negs=N)
+        top = ev.topk(20, mask_indptr=g.train_indptr, mask_items=g.train_items)
+        ev.close()
+        r = metrics.evaluate_topk(test, top, ms, quiet=True, by_user_id=True)
+        return r[ms[0]], r[ms[1]]
+
+    def oracle_run(seed):
+        uo, io = synthetic.init_embeddings(g.num_users, g.num_items, d, seed=seed)
+        ora = orc.Engine(g.clicks, uo, io, num_negs=N, clip_val=clip, l_r=lr)
+        losses = [ora.train_one_epoch(num_threads=8) for _ in range(epochs)]
+        return uo, io, losses
+
+    with ThreadPoolExecutor(max_workers=2) as pool:
+        futures = [pool.submit(oracle_run, s) for s in seeds]
+        gpu, name = [], None
+        for seed in seeds:
+            uw, iw = synthetic.init_embeddings(g.num_users, g.num_items, d, seed=seed)
+            eng = abi.Engine(g.clicks, uw, iw, num_negs=N, seed=seed, clip_val=clip, l_r=lr, flags=abi.FLAG_LAZY_SYNC)
+            losses = [eng.train_one_epoch() for _ in range(epochs)]
+            eng.sync_to_host()
+            name = eng.kernel_name
+            eng.close()
+            gpu.append(rank_and_score(uw, iw) + (losses[-1],))
+        ora = []
+        for f in futures:
+            uo, io, losses = f.result()
+            ora.append(rank_and_score(uo, io) + (losses[-1],))
+    gpu, ora = np.array(gpu), np.array(ora)
+    print(f"{shape} clusters={n_clusters} {name}\n gpu    (Recall, NDCG, final loss) per seed:\n{gpu}\n oracle:\n{ora}")
+    return gpu, ora, name
+
+
+def test_recall_ndcg_parity_yelp18_config():
+    """BASELINE.json configs[2] at the Yelp18 yaml's hyper-parameters (d=128, 64 negatives, clip_val 0.1, lr 0.01, 8 epochs;
+    Yelp18/MF_CCL/configs/config0.yaml:8-28) on the Yelp18-shaped graph with latent structure (64 user/item clusters: the
+    ranking then depends on the learned geometry, and the 8-thread oracle agrees with itself to ~5e-4 between seeds, which
+    the popularity-only graph does not: its Recall moves by +-6e-3 between oracle runs at this config).  The default
+    launch plan (one 8-wave workgroup per compute unit = 256 interactions in flight, positives by float atomics,
+    negatives by the late re-read write-back) must hold the north-star tolerance: mean Recall@20 / NDCG@20 over the seeds
+    within +-1e-3 of the oracle's, and the final-epoch training loss within 3 %."""
+    gpu, ora, name = _statistical_parity("yelp18", n_clusters=64, epochs=8, clip=0.1, seeds=(1, 2, 3, 4))
+    assert "<32,4,16,8>" in name and "upd=0x1c" in name and "streams=256" in name, name
+    # single runs of either side scatter by ~+-6e-4 around their mean (profiles/r02_yelp18_policy_sweep.txt): four seeds per
+    # side resolve the 1e-3 tolerance on the means
+    assert np.ptp(ora[:, 0]) < 3e-3 and np.ptp(ora[:, 1]) < 3e-3
+    assert ora[:, 0].mean() > 0.02                                            # the model learned something
+    assert abs(gpu[:, 0].mean() - ora[:, 0].mean()) <= 1e-3, (gpu, ora)
+    assert abs(gpu[:, 1].mean() - ora[:, 1].mean()) <= 1e-3, (gpu, ora)
+    assert abs(gpu[:, 2].mean() - ora[:, 2].mean()) <= 0.03 * ora[:, 2].mean(), (gpu, ora)
+
+
+def test_recall_ndcg_parity_gowalla_config():
+    """Full-size Gowalla shape at this fork's Gowalla yaml (d=128, 64 negatives, clip_val 0.1, 8 epochs;
+    Gowalla/MF_CCL/configs/config0.yaml:8-28), clustered graph, same criterion as the Yelp18 config."""
+    gpu, ora, name = _statistical_parity("gowalla", n_clusters=64, epochs=8, clip=0.1, seeds=(1, 2))
+    assert "upd=0x1c" in name, name
+    assert abs(gpu[:, 0].mean() - ora[:, 0].mean()) <= 1e-3, (gpu, ora)
+    assert abs(gpu[:, 1].mean() - ora[:, 1].mean()) <= 1e-3, (gpu, ora)
+    assert abs(gpu[:, 2].mean() - ora[:, 2].mean()) <= 0.03 * ora[:, 2].mean(), (gpu, ora)
+
+
+def test_recall_ndcg_parity_amazonbooks_clustered():
+    """The headline config (AmazonBooks yaml: d=64, 16 negatives, clip_val 1.0, 5 epochs) on the clustered variant of the
+    AmazonBooks-shaped graph — the more discriminating twin of test_recall_ndcg_parity_amazonbooks_shape."""
+    gpu, ora, name = _statistical_parity("amazonbooks", n_clusters=64, epochs=5, clip=1.0, seeds=(2022, 7))
+    assert "<16,4,16,1>" in name and "upd=0xc" in name, name
+    assert abs(gpu[:, 0].mean() - ora[:, 0].mean()) <= 1e-3, (gpu, ora)
+    assert abs(gpu[:, 1].mean() - ora[:, 1].mean()) <= 1e-3, (gpu, ora)
 
 
 def test_overwrite_mode_loses_updates_at_gpu_concurrency():
     """Documents WHY the default is the atomic write-back: the reference's literal overwrite, run with thousands of
     concurrent streams, drops a large share of the updates of popular rows and the epoch loss stays visibly higher."""
-    g, d, N = synthetic.make_named("gowalla", scale=0.5)
+    g, d, N = synthetic.make_named("gowalla_pr1", scale=0.5)
     losses = {}
     for mode in (abi.UPDATE_OVERWRITE, abi.UPDATE_ATOMIC_WG):
         uw, iw = synthetic.init_embeddings(g.num_users, g.num_items, d, seed=1)
@@ -443,7 +509,7 @@ def test_topk_fused_matches_numpy_and_panel_path(U, I, d, k, case, monkeypatch):
 
 def test_topk_fused_large_equals_panel_path(monkeypatch):
     """At a size the dense numpy check is too slow for, the fused path must agree id for id with the panel path."""
-    g, d, N = synthetic.make_named("gowalla", scale=0.25)
+    g, d, N = synthetic.make_named("gowalla_pr1", scale=0.25)
     uw, iw = synthetic.init_embeddings(g.num_users, g.num_items, d, seed=3)
     eng = abi.Engine(g.clicks[:1].copy(), uw, iw, num_negs=N)
     fused = eng.topk(50, mask_indptr=g.train_indptr, mask_items=g.train_items)
