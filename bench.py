@@ -113,7 +113,7 @@ def hbm_resident_leg(dev, stream, interactions, steps=2):
     from heat_amd.cf import synthetic
     U, I, _, d, N = synthetic.SHAPES["synthetic_hbm"]
     T = interactions
-    clicks = synthetic.make_clicks_torch(U, I, T, dev, seed=2022)
+    clicks = synthetic.make_clicks_torch(U, I, T, dev, seed=2022, per_user=20)      # 200 M / 10 M interactions per user
     g = torch.Generator(device=dev)
     g.manual_seed(2022)
     user_w = torch.empty((U, d), device=dev, dtype=torch.float32).normal_(0.0, 0.01, generator=g)
@@ -134,8 +134,8 @@ def hbm_resident_leg(dev, stream, interactions, steps=2):
     B, B_rd = 16 * d * (N + 2) + 16, 8 * d * (N + 2) + 16
     traffic, src = replayed_traffic("r02_pmc_traffic_hbm.json", eng.kernel_name)
     out = roofline(B, B_rd, T * steps, kernel_ms, launches, 2 * (U + I) * d * 4, traffic, src)
-    out["workload"] = (f"synthetic 10M x 1M, d={d}, negs={N}: {T} interactions per launch, a sample of the 200M list "
-                       f"(a full pass is 83.6 TB of algorithmic traffic)")
+    out["workload"] = (f"synthetic 10M x 1M, d={d}, negs={N}: {T} interactions per launch = {T // 20} users spread over the whole "
+                       f"table x 20 interactions each, a sample of the 200M list (a full pass is 83.6 TB of algorithmic traffic)")
     out["kernel"] = eng.kernel_name
     out["samples_per_s"] = T * steps / dt
     eng.close()
@@ -230,6 +230,10 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
+    elif os.environ.get("HEAT_BENCH_FORCE_SYNC"):      # one-rank group: the N>1 exchange path on a one-GPU box
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
 
     # one side stream carries the engine kernels and the fused delta / apply passes of the item exchange; the RCCL
     # all-reduce runs on torch.distributed's own stream, ordered against this one by events (async collective)
@@ -279,7 +283,7 @@ def main():
     if args.shape == "synthetic_hbm":
         # BASELINE.json configs[4] as the main workload (profiling runs): every rank its own sample of the list
         T = args.interactions or 20_000_000
-        clicks = synthetic.make_clicks_torch(U, I, T, dev, seed=2022 + rank)
+        clicks = synthetic.make_clicks_torch(U, I, T, dev, seed=2022 + rank, per_user=20)
         g = torch.Generator(device=dev)
         g.manual_seed(2022)
         user_w = torch.empty((U, d), device=dev, dtype=torch.float32).normal_(0.0, 0.01, generator=g)

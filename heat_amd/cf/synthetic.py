@@ -170,16 +170,25 @@ def init_embeddings(num_users, num_items, emb_dim, seed=2022, std=1e-2):
     return np.ascontiguousarray(uw), np.ascontiguousarray(iw)
 
 
-def make_clicks_torch(num_users, num_items, n, device, seed=2022, zipf_s=1.0):
+def make_clicks_torch(num_users, num_items, n, device, seed=2022, zipf_s=1.0, per_user=0):
     """Interaction list for shapes too large for the numpy generator (synthetic-HBM config: 10 M users x 1 M items):
     built on the GPU with torch, returned as an int64 [n,2] tensor (same bit pattern as the u64 pairs of the C ABI),
     grouped by user, item popularity Zipf(s) over a random permutation.  (user,item) pairs may repeat; there is no
-    test split — this generator feeds bandwidth measurements, not Recall."""
+    test split — this generator feeds bandwidth measurements, not Recall.
+    per_user > 0: a SAMPLE of a longer list — n / per_user users drawn over the whole id range, each with per_user
+    interactions (the config's 200 M / 10 M = 20), so that the run length per user row is the full list's."""
     import torch
     gen = torch.Generator(device=device)
     gen.manual_seed(seed)
-    users = torch.randint(0, num_users, (n,), device=device, generator=gen, dtype=torch.int64)
-    users, _ = torch.sort(users)
+    if per_user > 0:
+        picked = torch.randint(0, num_users, (max(1, n // per_user),), device=device, generator=gen, dtype=torch.int64)
+        users = torch.sort(picked)[0].repeat_interleave(per_user)
+        if users.numel() < n:
+            users = torch.cat([users, users[-1:].expand(n - users.numel())])
+        users = users[:n].contiguous()
+    else:
+        users = torch.randint(0, num_users, (n,), device=device, generator=gen, dtype=torch.int64)
+        users, _ = torch.sort(users)
     ranks = torch.arange(1, num_items + 1, device=device, dtype=torch.float64)
     cdf = torch.cumsum(ranks.pow(-zipf_s), 0)
     cdf /= cdf[-1].clone()

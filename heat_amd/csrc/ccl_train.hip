@@ -924,7 +924,7 @@ static hipError_t launch_variant(const TrainArgs& a, uint32_t grid, int aux, hip
 // wave would need > ~20 groups.
 #define HEATCF_VARIANTS(X) \
     X(8, 1, 1) X(8, 2, 1) X(8, 4, 1) X(8, 8, 1) X(8, 16, 1) \
-    X(16, 2, 1) X(16, 4, 1) X(16, 8, 1) X(16, 16, 1) X(16, 16, 2) \
+    X(16, 2, 1) X(16, 4, 1) X(16, 8, 1) X(16, 16, 1) X(16, 16, 2) X(16, 2, 2) X(16, 1, 4) \
     X(32, 4, 1) X(32, 8, 1) X(32, 16, 1) X(32, 32, 1) X(32, 16, 2) X(32, 8, 4) X(32, 16, 4) X(32, 4, 8) X(32, 2, 16) \
     X(64, 8, 1) X(64, 16, 1) X(64, 16, 2) X(64, 16, 4) X(64, 25, 4) X(64, 13, 8) X(64, 16, 8)
 

@@ -159,7 +159,12 @@ int make_plan(const heat_cf_config* cfg, uint64_t data_rows, uint64_t fill, Plan
     if (cfg->use_aggregator) in_flight = 0.56 * std::min(1.0, 17.0 / (rows_per_interaction + (double)history_rows));
     else if (wide) in_flight = can_reread ? 0.45 : 0.15;
     p->cap_items = (uint32_t)std::min<uint64_t>(0xFFFFFFFFull, (uint64_t)(in_flight * (double)cfg->num_items / rows_per_interaction));
-    p->cap_users = (uint32_t)std::min<uint64_t>(0xFFFFFFFFull, (uint64_t)(0.058 * (double)cfg->num_users));
+    // A stream walks at least 256 consecutive interactions (half a `schedule(dynamic,512)` chunk of the reference,
+    // train/engine.cpp:327): shorter slices cut the runs of heavy users into many pieces that train the same user row
+    // concurrently from one starting value.  Measured with 8 user shards of the AmazonBooks-shaped graph
+    // (profiles/r02_sim_shards.txt): 1024 streams per shard (290 interactions each) hold Recall@20 / NDCG@20 within 1e-3 of
+    // single-engine training, 3017 streams per shard (98 each) lose 4e-3.
+    p->cap_users = (uint32_t)std::min<uint64_t>(0xFFFFFFFFull, std::max<uint64_t>(1, data_rows / 256));
     uint64_t streams = std::min<uint64_t>(p->cap_items, p->cap_users);
     if (fill) streams = std::min(streams, fill);
     // a few workgroups more than a whole number per compute unit would make those units the tail of the launch

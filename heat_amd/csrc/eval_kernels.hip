@@ -8,8 +8,8 @@ namespace heatcf
 {
 
 // 64x64 output tile per 256-thread block, 4x4 outputs per thread, K staged through LDS in slabs of 32.
-// fp32 multiply and add are kept UNFUSED and k runs left to right so a panel is bit-identical to the oracle's
-// sequential fp32 dot (oracle/cf_oracle.c dotf); the reference's Eigen GEMM order is unspecified.
+// One fused multiply-add per k, k left to right: bit-identical to the oracle's evaluate0 dot (oracle/cf_oracle.c dot_fma)
+// and to the matrix-core chain of the fused top-k (topk_fused.hip); the reference's Eigen GEMM order is unspecified.
 __global__ __launch_bounds__(256) void sim_panel_kernel(const float* __restrict__ U, const float* __restrict__ V,
                                                         float* __restrict__ S, uint32_t rows, uint32_t num_items,
                                                         uint32_t d)
@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void sim_panel_kernel(const float* __restrict_
 #pragma unroll
             for (int a = 0; a < 4; ++a)
 #pragma unroll
-                for (int b = 0; b < 4; ++b) acc[a][b] = __fadd_rn(acc[a][b], __fmul_rn(av[a], bv[b]));
+                for (int b = 0; b < 4; ++b) acc[a][b] = __fmaf_rn(av[a], bv[b], acc[a][b]);
         }
         __syncthreads();
     }

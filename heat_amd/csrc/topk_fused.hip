@@ -4,10 +4,12 @@
 // -> sim[train] = -inf, argpartition, argsort (cf/metrics.py:21-29)  by one pass that keeps, per user, the running
 // k best (score, item) pairs in LDS while 64 x 128 score tiles are produced in registers and never stored.
 //
-// Arithmetic: every score is the fp32 dot of the oracle (oracle/cf_oracle.c dotf): multiply and add UNFUSED, k left to
-// right.  The tile loop therefore uses packed fp32 multiply + packed fp32 add (v_pk_mul_f32 / v_pk_add_f32, exact per
-// element) and not MFMA: on gfx950 the fp32 MFMA peak equals the packed-FMA VALU peak (157 TFLOP/s), so exact unfused
-// arithmetic costs a factor 2 against that bound and keeps the ranking bit-identical to the dense path.
+// Arithmetic: every score is the fp32 dot the oracle's evaluate0 defines (oracle/cf_oracle.c dot_fma): one fused
+// multiply-add per k, k ascending, starting from 0 — the reference's own order is unspecified (Eigen GEMM,
+// train/engine.cpp:394-398).  That chain is exactly what the fp32 matrix core computes: v_mfma_f32_32x32x2_f32
+// accumulates its two k steps as two fmaf's, so the 64 x 128 score tiles come from MFMA (157 TFLOP/s peak, the same as
+// the packed-FMA VALU peak, but it leaves the VALU free for staging and selection) and still rank bit-identically to the
+// dense path (sim_panel_kernel uses the same fmaf chain).
 //
 // Order: pairs are ranked by (score descending, item id ascending); NaN scores are never selected; masked items score
 // -inf and so can still fill the list when fewer than k unmasked items exist — exactly what topk_rows_kernel yields on
@@ -25,6 +27,7 @@ constexpr int TI = 128;    // items per tile
 constexpr int KS = 16;     // k-slab staged through LDS
 constexpr int LDA = TU + 4;
 constexpr int LDB = TI + 4;
+typedef float f16v __attribute__((ext_vector_type(16)));
 constexpr uint32_t NONE = 0xFFFFFFFFu;
 
 typedef float f2 __attribute__((ext_vector_type(2)));
@@ -35,8 +38,8 @@ constexpr int QW = 128;    // candidate queue entries per wave and tile
 // CAP = list slots per user (32 or 64): the short form leaves room for a fourth workgroup per CU
 template <int CAP> struct __attribute__((aligned(16))) SharedT
 {
-    float    a[KS][LDA];
-    float    b[KS][LDB];
+    float    a[KS / 2][LDA][2];    // [k pair][user][k parity]: the two lane halves of an MFMA read one 64-float span
+    float    b[KS / 2][LDB][2];
     float    topv[TU][CAP]; // per user: the k best so far, best first
     uint32_t topi[TU][CAP];
     float    thr_v[TU];                  // = entry k-1, the one a candidate has to beat
@@ -115,49 +118,30 @@ template <class Shared> __device__ __forceinline__ void push(Shared& s, uint32_t
     }
 }
 
-// operands of one k step: 4 user values (broadcast over the 16 lanes of a row) and 8 item values
-struct StepOps { f4 av, b0, b1; };
-
-template <class Shared> __device__ __forceinline__ StepOps tile_fetch(const Shared& s, int kq, int tx, int ty)
+// One k-slab on the matrix core.  Wave (wu, wi) owns users [32 wu, 32 wu + 32) x items [64 wi, 64 wi + 64) of the tile: two
+// 32 x 32 accumulators.  v_mfma_f32_32x32x2_f32 takes, per lane l, A[l % 32][l / 32] and B[l / 32][l % 32]: lane half h
+// supplies k = 2 kp + h, so k runs in ascending order through the chain of MFMAs.
+template <class Shared>
+__device__ __forceinline__ void mfma_step(const Shared& s, int kp, int wu, int wi, int n, int h, f16v& acc0, f16v& acc1)
 {
-    StepOps o;
-    o.av = *(const f4*)&s.a[kq][ty * 4];
-    o.b0 = *(const f4*)&s.b[kq][tx * 4];
-    o.b1 = *(const f4*)&s.b[kq][64 + tx * 4];
-    return o;
+    const float a = s.a[kp][wu * 32 + n][h];
+    const float b0 = s.b[kp][wi * 64 + n][h];
+    const float b1 = s.b[kp][wi * 64 + 32 + n][h];
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
 }
 
-// acc[a][c] += a-row value * b-row pair, product and sum rounded separately
-__device__ __forceinline__ void tile_fma(const StepOps& o, f2 (&acc)[4][4])
+template <bool FULL, class Shared>
+__device__ __forceinline__ void tile_slab_mfma(const Shared& s, int kpairs, int wu, int wi, int n, int h, f16v& acc0, f16v& acc1)
 {
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
+    if constexpr (FULL)
     {
-        const f2 aa = f2{o.av[a], o.av[a]};
-        acc[a][0] = acc[a][0] + aa * f2{o.b0[0], o.b0[1]};
-        acc[a][1] = acc[a][1] + aa * f2{o.b0[2], o.b0[3]};
-        acc[a][2] = acc[a][2] + aa * f2{o.b1[0], o.b1[1]};
-        acc[a][3] = acc[a][3] + aa * f2{o.b1[2], o.b1[3]};
+#pragma unroll
+        for (int kp = 0; kp < KS / 2; ++kp) mfma_step(s, kp, wu, wi, n, h, acc0, acc1);
     }
-}
-
-template <class Shared> __device__ __forceinline__ void tile_step(const Shared& s, int kq, int tx, int ty, f2 (&acc)[4][4])
-{
-    tile_fma(tile_fetch(s, kq, tx, ty), acc);
-}
-
-// a full slab with the LDS reads of step k+1 in flight while step k multiplies
-template <class Shared> __device__ __forceinline__ void tile_slab(const Shared& s, int tx, int ty, f2 (&acc)[4][4])
-{
-    StepOps cur = tile_fetch(s, 0, tx, ty);
-#pragma unroll
-    for (int kq = 0; kq < KS; ++kq)
+    else
     {
-        StepOps nxt = cur;
-        if (kq + 1 < KS) nxt = tile_fetch(s, kq + 1, tx, ty);
-        __builtin_amdgcn_sched_barrier(0); // keep the fetch ahead of the arithmetic it overlaps with
-        tile_fma(cur, acc);
-        cur = nxt;
+        for (int kp = 0; kp < kpairs; ++kp) mfma_step(s, kp, wu, wi, n, h, acc0, acc1);
     }
 }
 
@@ -187,12 +171,13 @@ __device__ __forceinline__ void load_slab(const FusedArgs& p, uint32_t u0, uint3
     gb1 = *(const f4*)(p.V + ((size_t)min(i0 + 64u + (uint32_t)sr, last) * d + kk));
 }
 
-template <int CAP> __global__ __launch_bounds__(256, CAP == 32 ? 4 : 3) void topk_fused_kernel(FusedArgs p)
+template <int CAP> __global__ __launch_bounds__(256, 3) void topk_fused_kernel(FusedArgs p)
 {
     typedef SharedT<CAP> Shared;
     __shared__ Shared s;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int tx = tid & 15, ty = tid >> 4;
+    const int wu = wave & 1, wi = wave >> 1;   // the wave's 32-user x 64-item corner of the tile
+    const int n = lane & 31, h = lane >> 5;    // MFMA lane coordinates: column / k parity (operands), column / row half (results)
     const uint32_t u0 = blockIdx.x * (uint32_t)TU;
     const uint32_t ntiles = (p.num_items + TI - 1) / TI;
     const uint32_t t_begin = blockIdx.y * p.tiles_per_split;
@@ -253,102 +238,77 @@ template <int CAP> __global__ __launch_bounds__(256, CAP == 32 ? 4 : 3) void top
             }
         }
 
-        f2 acc[4][4];
+        f16v acc0, acc1;
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int b = 0; b < 4; ++b) acc[a][b] = f2{0.0f, 0.0f};
+        for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
 
         // slab s+1 travels from L2 into registers while slab s is multiplied out of LDS
         if (tile == t_begin) load_slab(p, u0, i0, 0, sr, sc, ga, gb0, gb1);
         for (uint32_t k0 = 0; k0 < d; k0 += KS)
         {
             __syncthreads(); // previous slab fully consumed
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-            {
-                s.a[sc + j][sr] = ga[j];
-                s.b[sc + j][sr] = gb0[j];
-                s.b[sc + j][64 + sr] = gb1[j];
-            }
+            *(f2*)&s.a[sc / 2][sr][0] = f2{ga[0], ga[1]};
+            *(f2*)&s.a[sc / 2 + 1][sr][0] = f2{ga[2], ga[3]};
+            *(f2*)&s.b[sc / 2][sr][0] = f2{gb0[0], gb0[1]};
+            *(f2*)&s.b[sc / 2 + 1][sr][0] = f2{gb0[2], gb0[3]};
+            *(f2*)&s.b[sc / 2][64 + sr][0] = f2{gb1[0], gb1[1]};
+            *(f2*)&s.b[sc / 2 + 1][64 + sr][0] = f2{gb1[2], gb1[3]};
             __syncthreads();
             if (k0 + KS < d) load_slab(p, u0, i0, k0 + KS, sr, sc, ga, gb0, gb1);
             else if (tile + 1 < t_end) load_slab(p, u0, i0 + TI, 0, sr, sc, ga, gb0, gb1); // lands during selection
-            const int kmax = (d - k0) < (uint32_t)KS ? (int)(d - k0) : KS;
-            if (kmax == KS)
-            {
-                tile_slab(s, tx, ty, acc);
-            }
-            else
-            {
-                for (int kq = 0; kq < kmax; ++kq) tile_step(s, kq, tx, ty, acc);
-            }
+            const int kmax = (d - k0) < (uint32_t)KS ? (int)(d - k0) : KS;   // emb_dim % 4 == 0: always even
+            if (kmax == KS) tile_slab_mfma<true>(s, KS / 2, wu, wi, n, h, acc0, acc1);
+            else tile_slab_mfma<false>(s, kmax / 2, wu, wi, n, h, acc0, acc1);
         }
         __syncthreads(); // mbits of this tile visible; LDS slabs free
 
-        // thread's outputs: out[a][c] = user ty*4 + a, item i0 + (c>>2)*64 + tx*4 + (c&3); train items score -inf
-        float out[4][8];
+        // lane's results: acc_c[r] = user 32 wu + 8 (r / 4) + 4 h + (r % 4), item i0 + 64 wi + 32 c + n; train items score -inf
+        const uint32_t it0 = i0 + (uint32_t)(wi * 64 + n), it1 = it0 + 32u;
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
+        for (int q = 0; q < 4; ++q)
         {
-            const uint32_t u = (uint32_t)(ty * 4 + a);
+            const f4 t4 = *(const f4*)&s.thr_v[wu * 32 + 8 * q + 4 * h];
 #pragma unroll
-            for (int c = 0; c < 8; ++c) out[a][c] = acc[a][c >> 1][c & 1];
-            const uint32_t m8 = ((s.mbits[u][tx >> 3] >> ((tx & 7) * 4)) & 0xFu) |
-                                (((s.mbits[u][2 + (tx >> 3)] >> ((tx & 7) * 4)) & 0xFu) << 4);
-            if (m8)
+            for (int j = 0; j < 4; ++j)
             {
-#pragma unroll
-                for (int c = 0; c < 8; ++c)
-                    if ((m8 >> c) & 1u) out[a][c] = -INFINITY;
-            }
-        }
-        // a candidate is rare after the first tiles: one max and one compare per user row decide for all 8 outputs
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-        {
-            const uint32_t u = (uint32_t)(ty * 4 + a);
-            const float tv = s.thr_v[u];
-            const float vmax = fmaxf(fmaxf(fmaxf(out[a][0], out[a][1]), fmaxf(out[a][2], out[a][3])),
-                                     fmaxf(fmaxf(out[a][4], out[a][5]), fmaxf(out[a][6], out[a][7])));
-#ifdef TOPK_EXPERIMENT_NO_SELECT // timing experiment only: scores are produced, nothing is ranked
-            if (vmax == 12345.678f)
-#else
-            if (!(vmax < tv) && u0 + u < p.rows)
-#endif
-            {
-#pragma unroll
-                for (int c = 0; c < 8; ++c)
+                const int r = 4 * q + j;
+                const uint32_t u = (uint32_t)(wu * 32 + 8 * q + 4 * h + j);
+                const uint2 mw = *(const uint2*)&s.mbits[u][wi * 2];
+                if ((mw.x >> n) & 1u) acc0[r] = -INFINITY;
+                if ((mw.y >> n) & 1u) acc1[r] = -INFINITY;
+                // a candidate is rare after the first tiles: most waves skip the queueing altogether
+                const bool live = u0 + u < p.rows;
+                const bool c0 = live && it0 < p.num_items && !(acc0[r] < t4[j]);
+                const bool c1 = live && it1 < p.num_items && !(acc1[r] < t4[j]);
+                if (__ballot(c0 || c1) != 0ull)
                 {
-                    const uint32_t item = i0 + (uint32_t)((c >> 2) * 64 + tx * 4 + (c & 3));
-                    if (item < p.num_items && !(out[a][c] < tv)) push(s, u, item, out[a][c]);
+                    if (c0) push(s, u, it0, acc0[r]);
+                    if (c1) push(s, u, it1, acc1[r]);
                 }
             }
         }
         __syncthreads();
-        const uint32_t n = max(max(s.qn[0], s.qn[1]), max(s.qn[2], s.qn[3]));
-        if (n <= (uint32_t)QW)
+        const uint32_t nq = max(max(s.qn[0], s.qn[1]), max(s.qn[2], s.qn[3]));
+        if (nq <= (uint32_t)QW)
         {
-            if (n) drain(s, k, wave, lane);
+            if (nq) drain(s, k, wave, lane);
         }
         else
         {
             // more candidates than a queue holds (first tiles, or scores arriving in ascending order): one output
             // per thread and round, i.e. at most 64 per wave, against the thresholds the earlier rounds raised
-            for (int r = 0; r < 32; ++r)
+            for (int rnd = 0; rnd < 32; ++rnd)
             {
                 __syncthreads();
                 if (tid < 4) s.qn[tid] = 0;
                 __syncthreads();
-                const int a = r >> 3, c = r & 7;
-                const uint32_t u = (uint32_t)(ty * 4 + a);
-                const uint32_t item = i0 + (uint32_t)((c >> 2) * 64 + tx * 4 + (c & 3));
+                const int r = rnd >> 1, c = rnd & 1;
+                const uint32_t u = (uint32_t)(wu * 32 + 8 * (r >> 2) + 4 * h + (r & 3));
+                const uint32_t item = i0 + (uint32_t)(wi * 64 + 32 * c + n);
                 float v = 0.0f;
 #pragma unroll
-                for (int a2 = 0; a2 < 4; ++a2)
-#pragma unroll
-                    for (int c2 = 0; c2 < 8; ++c2)
-                        if (a2 == a && c2 == c) v = out[a2][c2];
+                for (int r2 = 0; r2 < 16; ++r2)
+                    if (r2 == r) v = c ? acc1[r2] : acc0[r2];
                 if (u0 + u < p.rows && item < p.num_items && !(v < s.thr_v[u])) push(s, u, item, v);
                 __syncthreads();
                 drain(s, k, wave, lane);

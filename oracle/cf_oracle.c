@@ -518,6 +518,16 @@ float orc_train_one_epoch(orc_engine* e, int num_threads, int sampler_call, uint
     return (float)(local_loss / (double)iterations); /* :383-385 */
 }
 
+/* Dot product of evaluate0: one fused multiply-add per k, k ascending, from 0.  The reference computes sim = U * V^T with
+ * an Eigen GEMM (train/engine.cpp:394-398) whose summation order is unspecified; the order fixed here is the one the
+ * fp32 matrix core executes, so the GPU ranking can be checked bit for bit. */
+static inline float dot_fma(const float* a, const float* b, uint64_t d)
+{
+    float acc = 0.0f;
+    for (uint64_t k = 0; k < d; ++k) acc = fmaf(a[k], b[k], acc);
+    return acc;
+}
+
 /* train/engine.cpp:388-400 */
 void orc_evaluate0(const orc_engine* e, float* sim)
 {
@@ -526,6 +536,6 @@ void orc_evaluate0(const orc_engine* e, float* sim)
     for (uint64_t u = 0; u < U; ++u)
     {
         const float* ur = e->user_w + u * d;
-        for (uint64_t i = 0; i < I; ++i) sim[u * I + i] = dotf(ur, e->item_w + i * d, d);
+        for (uint64_t i = 0; i < I; ++i) sim[u * I + i] = dot_fma(ur, e->item_w + i * d, d);
     }
 }

@@ -216,7 +216,9 @@ def test_launch_plan_host_logic():
     A = dict(emb_dim=64, num_negs=16, num_users=52643, num_items=91599, train_size=2380730)
     p = abi.plan(resident_workgroups=256 * 12, **A)
     assert (p["lanes_per_row"], p["groups_per_wave"], p["waves_per_workgroup"], p["negative_capacity"]) == (16, 4, 1, 16)
-    assert p["cap_items"] == int(0.56 * 91599 / 17) == 3017 and p["cap_users"] == int(0.058 * 52643)
+    assert p["cap_items"] == int(0.56 * 91599 / 17) == 3017 and p["cap_users"] == 2380730 // 256
+    # a user shard of an 8-GPU job (297 591 interactions): a stream still walks >= 256 interactions
+    assert abi.plan(resident_workgroups=256 * 12, **dict(A, num_users=6580, train_size=297591))["streams"] == 297591 // 256 == 1162
     assert p["streams"] == 3017 and p["update_mode"] == "ATOMIC_POS" and p["update_bits"] == 0xC and p["coherence"] == "device"
     # fewer resident workgroups than the cap: the chip is the limit
     assert abi.plan(resident_workgroups=1024, **A)["streams"] == 1024

@@ -423,6 +423,44 @@ def test_recall_ndcg_parity_amazonbooks_clustered():
     assert abs(gpu[:, 1].mean() - ora[:, 1].mean()) <= 1e-3, (gpu, ora)
 
 
+def test_eight_user_shards_match_single_engine_recall_ndcg():
+    """BASELINE.json configs[3] without the wires: the AmazonBooks-shaped graph cut into 8 user shards (cf/main.py:51-57),
+    one real HIP engine per shard taking turns on this GPU, item-table deltas exchanged twice per epoch with the other
+    shards' deltas arriving one window late — exactly what `bench.py --gpus 8` runs per rank (ItemSync overlap; the
+    all-reduce is a device-side sum over the 8 delta buffers here, tests/shard_sim.py).  Recall@20 / NDCG@20 after the
+    yaml's 5 epochs must stay within +-1e-3 of single-engine training on the whole graph, with each shard engine on its
+    own default launch plan (a stream walks >= 256 interactions: 1162 streams per shard)."""
+    import types
+    from heat_amd.cf import metrics
+    from tests.shard_sim import train_sharded
+    g, d, N = synthetic.make_named("amazonbooks")
+    uw0, iw0 = synthetic.init_embeddings(g.num_users, g.num_items, d, seed=2022)
+    ep = g.test_indptr.astype(np.int64)
+    test = types.SimpleNamespace(user_items_dic={u: g.test_items[ep[u]:ep[u + 1]].tolist()
+                                                 for u in range(g.num_users) if ep[u + 1] > ep[u]})
+    ms = ["Recall(k=20)", "NDCG(k=20)"]
+
+    def rank_and_score(uw, iw):
+        ev = abi.Engine(g.clicks[:1].copy(), uw, iw, num_negs=N)
+        top = ev.topk(20, mask_indptr=g.train_indptr, mask_items=g.train_items)
+        ev.close()
+        r = metrics.evaluate_topk(test, top, ms, quiet=True, by_user_id=True)
+        return r[ms[0]], r[ms[1]]
+
+    uw, iw = uw0.copy(), iw0.copy()
+    eng = abi.Engine(g.clicks, uw, iw, num_negs=N, seed=2022, flags=abi.FLAG_LAZY_SYNC)
+    for _ in range(5):
+        eng.train_one_epoch()
+    eng.sync_to_host()
+    eng.close()
+    single = rank_and_score(uw, iw)
+    su, si, losses, name = train_sharded(g, uw0, iw0, num_negs=N, world=8, epochs=5, windows_per_epoch=2, overlap=True, seed=2022)
+    sharded = rank_and_score(su, si)
+    print("single", single, "8 shards", sharded, name, losses)
+    assert "streams=1162" in name, name
+    assert abs(sharded[0] - single[0]) <= 1e-3 and abs(sharded[1] - single[1]) <= 1e-3, (single, sharded)
+
+
 def test_overwrite_mode_loses_updates_at_gpu_concurrency():
     """Documents WHY the default is the atomic write-back: the reference's literal overwrite, run with thousands of
     concurrent streams, drops a large share of the updates of popular rows and the epoch loss stays visibly higher."""
