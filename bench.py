@@ -225,15 +225,21 @@ def main():
         local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1 or "RANK" in os.environ:
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
-    elif os.environ.get("HEAT_BENCH_FORCE_SYNC"):      # one-rank group: the N>1 exchange path on a one-GPU box
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    # RCCL prints a version banner on stdout when its communicator comes up: keep stdout for the ONE JSON line
+    with stdout_to_stderr():
+        if world > 1 or "RANK" in os.environ:
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=dev)
+            else:
+                dist.init_process_group(backend)
+        elif os.environ.get("HEAT_BENCH_FORCE_SYNC"):      # one-rank group: the N>1 exchange path on a one-GPU box
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        if dist.is_initialized():
+            warm = torch.zeros(1, device=dev)
+            dist.all_reduce(warm)
+            torch.cuda.synchronize()
 
     # one side stream carries the engine kernels and the fused delta / apply passes of the item exchange; the RCCL
     # all-reduce runs on torch.distributed's own stream, ordered against this one by events (async collective)

@@ -9,7 +9,9 @@ Synchronisation rule.  Between two syncs every rank trains a window of its own s
     W_item <- W_ref + sum_r (W_item,r - W_ref)            (mode "sum": every rank's updates are applied, the cross-GPU
                                                             analogue of the in-GPU scatter-add; default)
     W_item <- mean_r W_item,r                              (mode "mean": the fork's intent, engine.cpp:366-375)
-where W_ref is the table right after the previous sync.  The persistent gradient rows G stay local (the reference
+where W_ref is the table right after the previous sync.  The exchange is delta -> all-reduce -> apply (two fused HIP
+passes of the C ABI around ONE collective); with overlap=True the all-reduce of a window runs while the next window
+trains and the other ranks' deltas are added one window late (class ItemSync).  The persistent gradient rows G stay local (the reference
 never communicates them).  With behaviour aggregation on, the d x d aggregator matrix W0 is replicated and averaged
 over ranks at the same points (engine.cpp:355-359: MPI_Allreduce SUM, then / world_size).  Window length: `sync_interactions` per rank; by default streams x refresh_interval
 (refresh_interval is a per-worker step count in the reference — negative_samplers/random_tile_negative_sampler.cpp:33 —
@@ -222,7 +224,8 @@ class ShardedTrainer:
 
     def __init__(self, clicks, user_w, item_w, *, num_negs, rank=None, world_size=None, device=None, seed=2022,
                  refresh_interval=8192, sync_interactions=0, mode="sum", engine_factory=None, balance="users",
-                 his=None, masks=None, w0=None, negatives=None, overlap=False, defer_final=False, **cfg_kwargs):
+                 his=None, masks=None, w0=None, negatives=None, overlap=False, defer_final=False, windows_per_epoch=0,
+                 **cfg_kwargs):
         import torch
         import torch.distributed as dist
         self.torch = torch
@@ -281,6 +284,7 @@ class ShardedTrainer:
         self.sync = ItemSync(self.engine, self.t_item, self.world, refresh_interval=refresh_interval,
                              sync_interactions=sync_interactions, mode=mode,
                              mean_tensors=(self.t_w0,) if self.aggregate else (), overlap=overlap, defer_final=defer_final,
+                             windows_per_epoch=windows_per_epoch,
                              negatives=None if negatives is None else
                              np.ascontiguousarray(negatives[base:base + self.shard.shape[0]], dtype=np.uint64))
 

@@ -58,6 +58,8 @@ def _main_distributed(args, model_config, cf_config, train_data, test_data, seed
                              refresh_interval=cf_config.refresh_interval, neg_sampler=cf_config.neg_sampler,
                              tile_size=cf_config.tile_size,
                              sync_interactions=int(model_config.get('sync_interactions', 0)),   # 0: streams x refresh_interval, capped at one epoch
+                             windows_per_epoch=int(model_config.get('sync_windows', 0)),        # > 0: that many equal windows per epoch instead
+                             overlap=bool(model_config.get('sync_overlap', False)),              # all-reduce of a window hidden behind the next one
                              num_streams=int(cf_config.num_streams), update_mode=int(cf_config.update_mode),
                              **agg)
     lo, hi = trainer.lo, trainer.hi

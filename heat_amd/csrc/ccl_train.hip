@@ -956,17 +956,26 @@ bool pick_variant(uint32_t emb_dim, uint32_t num_negs, bool single_wave, int* lp
         }
     }
     int best_cap = 0, best_g = 0, best_w = 0;
-    // smallest capacity that fits; among equals the fewest register groups per wave, down to 4 (= most waves per workgroup):
-    // measured at Yelp18 shape with 256 streams <32,4,8> 31.1 ms > <32,2,16> 37.2 = <32,8,4> 37.4 ms per epoch
-    // (profiles/r02_yelp18_policy_sweep.txt); uncapped, round 1: <32,8,4> 0.81 > <32,16,2> 0.78 > <32,32,1> 0.74 of HBM peak;
-    // splitting a small interaction (<= 4 groups) over two waves is slower (<16,2,2> 0.75 vs <16,4,1> 0.85)
-#define X(L, G, W)                                                                                   \
-    if (L == lpr && (uint32_t)(G * R * W) >= num_negs && (!single_wave || W == 1) &&                   \
-        (best_cap == 0 || G * R * W < best_cap || (G * R * W == best_cap && G < best_g && G >= 4)))    \
-    {                                                                                                  \
-        best_cap = G * R * W;                                                                          \
-        best_g = G;                                                                                    \
-        best_w = W;                                                                                    \
+    // The tightest capacity that fits decides the candidates (up to 10 % slack); among them the fewest register groups per
+    // wave, down to 4 (= most waves per workgroup).  Measured (profiles/r02_variant_sweep.txt): Yelp18 shape with 256
+    // streams <32,4,8> 31.1 ms > <32,2,16> 37.2 = <32,8,4> 37.4 ms per epoch; synthetic 10 M x 1 M shape (d 256, 100
+    // negatives, HBM-resident) <64,13,8> 12.8 M > <64,25,4> 9.3 M = <64,16,8> 9.1 M samples/s; splitting a small
+    // interaction (<= 4 groups) over several waves is slower (AmazonBooks shard, 1162 streams: <16,4,1> 1.08 ms >
+    // <16,2,2> 1.20 > <16,1,4> 1.37 ms).
+    int tight = 0;
+#define X(L, G, W) \
+    if (L == lpr && (uint32_t)(G * R * W) >= num_negs && (!single_wave || W == 1) && (tight == 0 || G * R * W < tight)) tight = G * R * W;
+    HEATCF_VARIANTS(X)
+#undef X
+    const int slack = tight + tight / 10;
+#define X(L, G, W)                                                                                                       \
+    if (L == lpr && (uint32_t)(G * R * W) >= num_negs && G * R * W <= slack && (!single_wave || W == 1) &&                 \
+        (best_cap == 0 || (G >= 4 && (G < best_g || best_g < 4)) || (G == best_g && G * R * W < best_cap) ||               \
+         (best_g < 4 && G < 4 && G * R * W < best_cap)))                                                                  \
+    {                                                                                                                    \
+        best_cap = G * R * W;                                                                                            \
+        best_g = G;                                                                                                      \
+        best_w = W;                                                                                                      \
     }
     HEATCF_VARIANTS(X)
 #undef X

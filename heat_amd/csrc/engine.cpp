@@ -194,6 +194,10 @@ int make_plan(const heat_cf_config* cfg, uint64_t data_rows, uint64_t fill, Plan
     if (bits != 0u && coh != HEAT_CF_COHERENCE_DEVICE)
         return fail(HEAT_CF_EINVAL, "atomic / re-read update modes need HEAT_CF_COHERENCE_DEVICE");
     if ((bits & 0x10u) && cfg->use_aggregator) return fail(HEAT_CF_EUNSUP, "the late re-read write-back is not built for behaviour aggregation");
+    // The reference's literal overwrite loses updates in proportion to the number of concurrent workers (Recall@20 0.099 vs
+    // 0.209 at AmazonBooks shape with ~3000 streams, profiles/r01_recall_parity_overwrite_modes.txt): without an explicit
+    // num_streams it runs at a worker count the reference itself could have (64 OpenMP threads in the paper).
+    if (bits == 0u && !cfg->num_streams && !(cfg->flags & HEAT_CF_FLAG_SERIAL) && p->streams > 64u) p->streams = 64u;
     p->update_mode = um;
     p->upd_bits = bits;
     return HEAT_CF_OK;
@@ -830,7 +834,7 @@ static int topk_fused(heat_cf_engine* e, uint64_t u_begin, uint64_t u_end, uint3
     if (const char* pc = getenv("HEAT_CF_TOPK_PANEL")) // tests: walk several user panels with a small table
         panel_cap = std::max<uint64_t>(1, strtoull(pc, nullptr, 10));
     const uint64_t panel = std::min<uint64_t>(nu, panel_cap);
-    const uint32_t slots = 3 * e->cu_count; // 3 workgroups of 52 KB LDS per CU
+    const uint32_t slots = 2 * e->cu_count; // 2 workgroups (<= 256 VGPRs, <= 80 KB LDS each) per CU
     const uint64_t last = nu % panel ? nu % panel : panel;
     const size_t part_elems = (size_t)k * std::max<uint64_t>(panel * topk_fused_splits((uint32_t)panel, (uint32_t)I, slots),
                                                              last * topk_fused_splits((uint32_t)last, (uint32_t)I, slots));

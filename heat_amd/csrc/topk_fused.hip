@@ -24,7 +24,7 @@ namespace
 {
 constexpr int TU = 64;     // users per workgroup
 constexpr int TI = 128;    // items per tile
-constexpr int KS = 16;     // k-slab staged through LDS
+constexpr int KS = 32;     // k-slab staged through LDS
 constexpr int LDA = TU + 4;
 constexpr int LDB = TI + 4;
 typedef float f16v __attribute__((ext_vector_type(16)));
@@ -157,21 +157,44 @@ struct FusedArgs
     uint32_t*       part_i;
 };
 
-// One float4 of user row u0+sr and of item rows i0+sr, i0+64+sr at columns [k0+sc, k0+sc+4).  No branches: rows past
-// the end of a table are clamped to its last row and columns past emb_dim to its last float4 — such scores are
-// computed but never ranked (the filter checks user < rows, item < num_items; the k loop stops at emb_dim).
-// emb_dim % 4 == 0 and 16-byte aligned rows are checked on the host.
-__device__ __forceinline__ void load_slab(const FusedArgs& p, uint32_t u0, uint32_t i0, uint32_t k0, int sr, int sc,
-                                          f4& ga, f4& gb0, f4& gb1)
+// Registers of one slab in flight: two float4 of user row u0+sr and of item rows i0+sr, i0+64+sr at columns
+// [k0+sc, k0+sc+4) and [k0+16+sc, k0+16+sc+4).  No branches: rows past the end of a table are clamped to its last row and
+// columns past emb_dim to its last float4 — such scores are computed but never ranked (the filter checks user < rows,
+// item < num_items; the k loop stops at emb_dim).  emb_dim % 4 == 0 and 16-byte aligned rows are checked on the host.
+struct SlabRegs { f4 a[2], b0[2], b1[2]; };
+
+__device__ __forceinline__ void load_slab(const FusedArgs& p, uint32_t u0, uint32_t i0, uint32_t k0, int sr, int sc, SlabRegs& g)
 {
-    const uint32_t d = p.d, kk = min(k0 + (uint32_t)sc, d - 4u);
-    const uint32_t last = p.num_items - 1u;
-    ga  = *(const f4*)(p.U + ((size_t)min(u0 + (uint32_t)sr, p.rows - 1u) * d + kk));
-    gb0 = *(const f4*)(p.V + ((size_t)min(i0 + (uint32_t)sr, last) * d + kk));
-    gb1 = *(const f4*)(p.V + ((size_t)min(i0 + 64u + (uint32_t)sr, last) * d + kk));
+    const uint32_t d = p.d, last = p.num_items - 1u;
+    const float* ua = p.U + (size_t)min(u0 + (uint32_t)sr, p.rows - 1u) * d;
+    const float* v0 = p.V + (size_t)min(i0 + (uint32_t)sr, last) * d;
+    const float* v1 = p.V + (size_t)min(i0 + 64u + (uint32_t)sr, last) * d;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+    {
+        const uint32_t kk = min(k0 + (uint32_t)(sc + 16 * j), d - 4u);
+        g.a[j] = *(const f4*)(ua + kk);
+        g.b0[j] = *(const f4*)(v0 + kk);
+        g.b1[j] = *(const f4*)(v1 + kk);
+    }
 }
 
-template <int CAP> __global__ __launch_bounds__(256, 3) void topk_fused_kernel(FusedArgs p)
+template <class Shared> __device__ __forceinline__ void store_slab(Shared& s, int sr, int sc, const SlabRegs& g)
+{
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+    {
+        const int kp = sc / 2 + 8 * j;
+        *(f2*)&s.a[kp][sr][0] = f2{g.a[j][0], g.a[j][1]};
+        *(f2*)&s.a[kp + 1][sr][0] = f2{g.a[j][2], g.a[j][3]};
+        *(f2*)&s.b[kp][sr][0] = f2{g.b0[j][0], g.b0[j][1]};
+        *(f2*)&s.b[kp + 1][sr][0] = f2{g.b0[j][2], g.b0[j][3]};
+        *(f2*)&s.b[kp][64 + sr][0] = f2{g.b1[j][0], g.b1[j][1]};
+        *(f2*)&s.b[kp + 1][64 + sr][0] = f2{g.b1[j][2], g.b1[j][3]};
+    }
+}
+
+template <int CAP> __global__ __launch_bounds__(256, 2) void topk_fused_kernel(FusedArgs p)
 {
     typedef SharedT<CAP> Shared;
     __shared__ Shared s;
@@ -217,9 +240,18 @@ template <int CAP> __global__ __launch_bounds__(256, 3) void topk_fused_kernel(F
     }
     __syncthreads();
 
-    // staging map: one float4 of a user row, two of item rows, per thread and slab
+    // staging map: thread (sr, sc) carries columns sc..sc+3 and 16+sc..16+sc+3 of user row sr and item rows sr, 64+sr.
+    // Two slabs are always in flight (ring[0] = even slabs, ring[1] = odd slabs of a tile): a load is issued two slabs —
+    // at emb_dim 64 one whole tile — before it is consumed, so the L2 / Infinity-Cache latency hides behind the MFMAs.
     const int sr = tid >> 2, sc = (tid & 3) * 4;
-    f4 ga = f4{0, 0, 0, 0}, gb0 = ga, gb1 = ga;
+    SlabRegs ring[2];
+    ring[0].a[0] = ring[0].a[1] = ring[0].b0[0] = ring[0].b0[1] = ring[0].b1[0] = ring[0].b1[1] = f4{0, 0, 0, 0};
+    ring[1] = ring[0];
+    if (t_begin < t_end)
+    {
+        load_slab(p, u0, t_begin * (uint32_t)TI, 0, sr, sc, ring[0]);
+        if ((uint32_t)KS < d) load_slab(p, u0, t_begin * (uint32_t)TI, KS, sr, sc, ring[1]);
+    }
 
     for (uint32_t tile = t_begin; tile < t_end; ++tile)
     {
@@ -242,23 +274,24 @@ template <int CAP> __global__ __launch_bounds__(256, 3) void topk_fused_kernel(F
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
 
-        // slab s+1 travels from L2 into registers while slab s is multiplied out of LDS
-        if (tile == t_begin) load_slab(p, u0, i0, 0, sr, sc, ga, gb0, gb1);
-        for (uint32_t k0 = 0; k0 < d; k0 += KS)
+        for (uint32_t k0 = 0; k0 < d; k0 += 2 * KS)
         {
-            __syncthreads(); // previous slab fully consumed
-            *(f2*)&s.a[sc / 2][sr][0] = f2{ga[0], ga[1]};
-            *(f2*)&s.a[sc / 2 + 1][sr][0] = f2{ga[2], ga[3]};
-            *(f2*)&s.b[sc / 2][sr][0] = f2{gb0[0], gb0[1]};
-            *(f2*)&s.b[sc / 2 + 1][sr][0] = f2{gb0[2], gb0[3]};
-            *(f2*)&s.b[sc / 2][64 + sr][0] = f2{gb1[0], gb1[1]};
-            *(f2*)&s.b[sc / 2 + 1][64 + sr][0] = f2{gb1[2], gb1[3]};
-            __syncthreads();
-            if (k0 + KS < d) load_slab(p, u0, i0, k0 + KS, sr, sc, ga, gb0, gb1);
-            else if (tile + 1 < t_end) load_slab(p, u0, i0 + TI, 0, sr, sc, ga, gb0, gb1); // lands during selection
-            const int kmax = (d - k0) < (uint32_t)KS ? (int)(d - k0) : KS;   // emb_dim % 4 == 0: always even
-            if (kmax == KS) tile_slab_mfma<true>(s, KS / 2, wu, wi, n, h, acc0, acc1);
-            else tile_slab_mfma<false>(s, kmax / 2, wu, wi, n, h, acc0, acc1);
+#pragma unroll
+            for (int slot = 0; slot < 2; ++slot)
+            {
+                const uint32_t ks = k0 + (uint32_t)(slot * KS);
+                if (ks >= d) break;
+                __syncthreads(); // previous slab fully consumed
+                store_slab(s, sr, sc, ring[slot]);
+                __syncthreads();
+                // this slot's next slab: two slabs further in this tile, else the same slot of the next tile
+                const uint32_t nk = ks + 2u * (uint32_t)KS;
+                if (nk < d) load_slab(p, u0, i0, nk, sr, sc, ring[slot]);
+                else if (tile + 1 < t_end && (uint32_t)(slot * KS) < d) load_slab(p, u0, i0 + TI, slot * KS, sr, sc, ring[slot]);
+                const int kmax = (d - ks) < (uint32_t)KS ? (int)(d - ks) : KS;   // emb_dim % 4 == 0: always even
+                if (kmax == KS) tile_slab_mfma<true>(s, KS / 2, wu, wi, n, h, acc0, acc1);
+                else tile_slab_mfma<false>(s, kmax / 2, wu, wi, n, h, acc0, acc1);
+            }
         }
         __syncthreads(); // mbits of this tile visible; LDS slabs free
 

@@ -237,9 +237,11 @@ def test_launch_plan_host_logic():
     assert y["cap_items"] == int(0.45 * 38048 / 65) == 263
     assert (y["lanes_per_row"], y["groups_per_wave"], y["waves_per_workgroup"], y["streams"]) == (32, 4, 8, 256)
     assert y["update_mode"] == "REREAD_POS" and y["update_bits"] == 0x1C
-    # ... without device-coherent row traffic there is no fresh value to re-read: plain stores, bound 0.15
-    assert abi.plan(emb_dim=128, num_negs=64, num_users=31668, num_items=38048, train_size=1237259,
-                    coherence=abi.COHERENCE_PLAIN)["streams"] == int(0.15 * 38048 / 65)
+    # ... without device-coherent row traffic there is neither a fresh value to re-read nor an atomic: the reference's
+    # literal overwrite, which stays at a worker count the reference itself could have
+    yp = abi.plan(emb_dim=128, num_negs=64, num_users=31668, num_items=38048, train_size=1237259, coherence=abi.COHERENCE_PLAIN)
+    assert yp["cap_items"] == int(0.15 * 38048 / 65) and yp["update_mode"] == "OVERWRITE" and yp["streams"] == 64
+    assert abi.plan(update_mode=abi.UPDATE_OVERWRITE, **A)["streams"] == 64
     # few streams on a large table: collisions are rare, positives-atomic is enough
     assert abi.plan(emb_dim=128, num_negs=64, num_users=31668, num_items=38048, train_size=1237259, num_streams=64)["update_mode"] == "ATOMIC_POS"
     s_ = abi.plan(emb_dim=256, num_negs=100, num_users=10_000_000, num_items=1_000_000, train_size=200_000_000,

@@ -50,14 +50,14 @@ def assert_tables_close(a, b, scale, rtol=2e-4):
 
 @pytest.mark.parametrize("d,N,U,I,T", [
     (64, 16, 60, 400, 3000),     # AmazonBooks/Gowalla kernel variant <16,4>
-    (128, 64, 40, 600, 800),     # Yelp18 variant <32,32>
+    (128, 64, 40, 600, 800),     # Yelp18 config: <32,4> x 8 waves per workgroup
     (32, 4, 30, 200, 1500),      # <8,1>
     (256, 16, 20, 300, 600),     # <64,16>
     (64, 5, 30, 200, 1000),      # masked negative slots (N not a multiple of rows-per-instruction)
     (20, 3, 25, 300, 800),       # masked columns (emb_dim/4 = 5 of 8 lanes)
     (64, 100, 20, 2000, 300),    # <16,16> x 2 waves per workgroup
-    (256, 100, 12, 3000, 150),   # synthetic-HBM config: <64,16> x 8 waves per workgroup
-    (128, 100, 12, 3000, 150),   # <32,16> x 4 waves
+    (256, 100, 12, 3000, 150),   # synthetic-HBM config: <64,25> x 4 waves per workgroup
+    (128, 100, 12, 3000, 150),   # <32,16> x 4 waves (two id registers per lane)
 ])
 def test_serial_walk_matches_oracle(d, N, U, I, T):
     clicks, uw, iw = small_problem(U, I, T, d, seed=d * 7 + N)
@@ -462,13 +462,14 @@ def test_eight_user_shards_match_single_engine_recall_ndcg():
 
 
 def test_overwrite_mode_loses_updates_at_gpu_concurrency():
-    """Documents WHY the default is the atomic write-back: the reference's literal overwrite, run with thousands of
-    concurrent streams, drops a large share of the updates of popular rows and the epoch loss stays visibly higher."""
+    """Documents WHY the default is the atomic write-back: the reference's literal overwrite, run with more than a thousand
+    concurrent streams (forced: on its own the overwrite policy stays at 64), drops a large share of the updates of
+    popular rows and the epoch loss stays visibly higher."""
     g, d, N = synthetic.make_named("gowalla_pr1", scale=0.5)
     losses = {}
     for mode in (abi.UPDATE_OVERWRITE, abi.UPDATE_ATOMIC_WG):
         uw, iw = synthetic.init_embeddings(g.num_users, g.num_items, d, seed=1)
-        eng = abi.Engine(g.clicks, uw, iw, num_negs=N, seed=1, update_mode=mode, flags=abi.FLAG_LAZY_SYNC)
+        eng = abi.Engine(g.clicks, uw, iw, num_negs=N, seed=1, update_mode=mode, num_streams=1300, flags=abi.FLAG_LAZY_SYNC)
         losses[mode] = [eng.train_one_epoch() for _ in range(3)]
         eng.close()
     assert losses[abi.UPDATE_ATOMIC_WG][-1] < losses[abi.UPDATE_OVERWRITE][-1]
