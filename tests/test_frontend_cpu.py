@@ -230,7 +230,7 @@ def test_launch_plan_host_logic():
     assert abi.plan(coherence=abi.COHERENCE_PLAIN, **A)["update_mode"] == "OVERWRITE"
     with pytest.raises(ValueError):
         abi.plan(coherence=abi.COHERENCE_PLAIN, update_mode=abi.UPDATE_ATOMIC_WG, **A)
-    # variant table: Yelp18 (d128, N64) -> 32 lanes/row, 4 groups x 8 waves; synthetic-HBM (d256, N100) -> 25 groups x 4 waves
+    # variant table: Yelp18 (d128, N64) -> 32 lanes/row, 4 groups x 8 waves; synthetic-HBM (d256, N100) -> 13 groups x 8 waves (4 % capacity slack)
     y = abi.plan(emb_dim=128, num_negs=64, num_users=31668, num_items=38048, train_size=1237259)
     # 65 rows per interaction: 0.45 in-flight touches per item row with the late re-read write-back
     # (0.45 * 38048 / 65 = 263 streams, rounded down to one workgroup per compute unit)
@@ -246,7 +246,7 @@ def test_launch_plan_host_logic():
     assert abi.plan(emb_dim=128, num_negs=64, num_users=31668, num_items=38048, train_size=1237259, num_streams=64)["update_mode"] == "ATOMIC_POS"
     s_ = abi.plan(emb_dim=256, num_negs=100, num_users=10_000_000, num_items=1_000_000, train_size=200_000_000,
                   resident_workgroups=256)
-    assert (s_["lanes_per_row"], s_["groups_per_wave"], s_["waves_per_workgroup"], s_["streams"]) == (64, 25, 4, 256)
+    assert (s_["lanes_per_row"], s_["groups_per_wave"], s_["waves_per_workgroup"], s_["streams"]) == (64, 13, 8, 256)
     assert s_["update_mode"] == "ATOMIC_POS"          # 256 x 101 / 1 M = 0.03 in-flight touches per item row
     # masked shapes: emb_dim 20 -> 8 lanes/row (5 used); 5 negatives -> 1 group of 8 rows
     m = abi.plan(emb_dim=20, num_negs=5, num_users=100, num_items=1000, train_size=10)
