@@ -164,7 +164,15 @@ int make_plan(const heat_cf_config* cfg, uint64_t data_rows, uint64_t fill, Plan
     // concurrently from one starting value.  Measured with 8 user shards of the AmazonBooks-shaped graph
     // (profiles/r02_sim_shards.txt): 1024 streams per shard (290 interactions each) hold Recall@20 / NDCG@20 within 1e-3 of
     // single-engine training, 3017 streams per shard (98 each) lose 4e-3.
-    p->cap_users = (uint32_t)std::min<uint64_t>(0xFFFFFFFFull, std::max<uint64_t>(1, data_rows / 256));
+    // Wide interactions (the Yelp18 / Gowalla yaml: 64 negatives, clip_val 0.1) also bound the SHARE of an epoch that is in
+    // flight: every row's persistent gradient G accumulates over the epoch, and streams / data_rows is the staleness of a
+    // row relative to the updates it receives per epoch.  Clustered graphs at the yaml's 8 epochs
+    // (profiles/r02_yelp18_policy_sweep.txt): Yelp18 shape (1.24 M interactions) holds +-1e-3 at 256 streams and is at
+    // the edge at 400; the same tables with 0.81 M interactions and the Gowalla shape (0.81 M) hold it at 128-170 and lose
+    // 1.2e-3 - 2e-3 at 200-256; with 2 M interactions 256 holds and 400 is at the edge (+1.2e-3).  Bound: a stream walks at
+    // least 5600 interactions of such an epoch (Yelp18 shape: 220 streams, Gowalla shape: 144).
+    const uint64_t min_slice = (wide && !cfg->use_aggregator) ? 5600 : 256;
+    p->cap_users = (uint32_t)std::min<uint64_t>(0xFFFFFFFFull, std::max<uint64_t>(1, data_rows / min_slice));
     uint64_t streams = std::min<uint64_t>(p->cap_items, p->cap_users);
     if (fill) streams = std::min(streams, fill);
     // a few workgroups more than a whole number per compute unit would make those units the tail of the launch

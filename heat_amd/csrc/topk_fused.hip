@@ -206,6 +206,10 @@ template <int CAP> __global__ __launch_bounds__(256, 2) void topk_fused_kernel(F
     const uint32_t t_begin = blockIdx.y * p.tiles_per_split;
     const uint32_t t_end = min(ntiles, t_begin + p.tiles_per_split);
     const uint32_t d = p.d, k = p.k;
+    uint32_t ulive = 0u;       // bits 2r, 2r + 1: the user of result register r exists
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+        if (u0 + (uint32_t)(wu * 32 + 8 * (r >> 2) + 4 * h + (r & 3)) < p.rows) ulive |= 3u << (2 * r);
 
     for (int t = tid; t < TU * CAP; t += 256)
     {
@@ -295,8 +299,11 @@ template <int CAP> __global__ __launch_bounds__(256, 2) void topk_fused_kernel(F
         }
         __syncthreads(); // mbits of this tile visible; LDS slabs free
 
-        // lane's results: acc_c[r] = user 32 wu + 8 (r / 4) + 4 h + (r % 4), item i0 + 64 wi + 32 c + n; train items score -inf
+        // lane's results: acc_c[r] = user 32 wu + 8 (r / 4) + 4 h + (r % 4), item i0 + 64 wi + 32 c + n.
+        // (1) branch-free filter of the 32 raw scores against their users' thresholds: bit 2r + c of `cand`.  After the
+        //     first tiles a candidate is rare, so this — 4 LDS reads, 32 compares — is all the selection costs per tile.
         const uint32_t it0 = i0 + (uint32_t)(wi * 64 + n), it1 = it0 + 32u;
+        uint32_t cand = 0u;
 #pragma unroll
         for (int q = 0; q < 4; ++q)
         {
@@ -305,19 +312,27 @@ template <int CAP> __global__ __launch_bounds__(256, 2) void topk_fused_kernel(F
             for (int j = 0; j < 4; ++j)
             {
                 const int r = 4 * q + j;
-                const uint32_t u = (uint32_t)(wu * 32 + 8 * q + 4 * h + j);
-                const uint2 mw = *(const uint2*)&s.mbits[u][wi * 2];
-                if ((mw.x >> n) & 1u) acc0[r] = -INFINITY;
-                if ((mw.y >> n) & 1u) acc1[r] = -INFINITY;
-                // a candidate is rare after the first tiles: most waves skip the queueing altogether
-                const bool live = u0 + u < p.rows;
-                const bool c0 = live && it0 < p.num_items && !(acc0[r] < t4[j]);
-                const bool c1 = live && it1 < p.num_items && !(acc1[r] < t4[j]);
-                if (__ballot(c0 || c1) != 0ull)
-                {
-                    if (c0) push(s, u, it0, acc0[r]);
-                    if (c1) push(s, u, it1, acc1[r]);
-                }
+                cand |= (!(acc0[r] < t4[j]) ? 1u : 0u) << (2 * r);
+                cand |= (!(acc1[r] < t4[j]) ? 1u : 0u) << (2 * r + 1);
+            }
+        }
+        cand &= ulive & ((it0 < p.num_items ? 0x55555555u : 0u) | (it1 < p.num_items ? 0xAAAAAAAAu : 0u));
+        // (2) the rare part: a train item scores -inf (metrics.py:24) and is queued only while its user's list is not full
+        if (__ballot(cand != 0u) != 0ull)
+        {
+            uint32_t todo = cand;
+            while (todo != 0u)
+            {
+                const int b = __builtin_ctz(todo);
+                todo &= todo - 1u;
+                const int r = b >> 1, c = b & 1;
+                const uint32_t u = (uint32_t)(wu * 32 + 8 * (r >> 2) + 4 * h + (r & 3));
+                float v = 0.0f;
+#pragma unroll
+                for (int r2 = 0; r2 < 16; ++r2)
+                    if (r2 == r) v = c ? acc1[r2] : acc0[r2];
+                if ((s.mbits[u][wi * 2 + c] >> n) & 1u) v = -INFINITY;
+                if (!(v < s.thr_v[u])) push(s, u, c ? it1 : it0, v);
             }
         }
         __syncthreads();
@@ -342,6 +357,7 @@ template <int CAP> __global__ __launch_bounds__(256, 2) void topk_fused_kernel(F
 #pragma unroll
                 for (int r2 = 0; r2 < 16; ++r2)
                     if (r2 == r) v = c ? acc1[r2] : acc0[r2];
+                if ((s.mbits[u][wi * 2 + c] >> n) & 1u) v = -INFINITY;
                 if (u0 + u < p.rows && item < p.num_items && !(v < s.thr_v[u])) push(s, u, item, v);
                 __syncthreads();
                 drain(s, k, wave, lane);

@@ -101,7 +101,8 @@ typedef struct heat_cf_config
     int32_t  device;            /* HIP device ordinal; -1 = current device */
     uint32_t num_streams;       /* concurrent sequential interaction streams (workgroups); 0 = auto: what fills the GPU,
                                    capped at 0.56 * num_items / (num_negs + 1) (0.45 above 17 rows per interaction) and
-                                   at data_rows / 256 (a stream walks at least 256 interactions) — the asynchrony
+                                   at data_rows / 256 (a stream walks at least 256 interactions; 5600 above 17 rows per
+                                   interaction) — the asynchrony
                                    validated against the oracle's Recall/NDCG at AmazonBooks and Yelp18 shape, DESIGN.md
                                    section 3 — rounded down to whole workgroups per compute unit */
     uint32_t update_mode;       /* HEAT_CF_UPDATE_* */

@@ -232,10 +232,11 @@ def test_launch_plan_host_logic():
         abi.plan(coherence=abi.COHERENCE_PLAIN, update_mode=abi.UPDATE_ATOMIC_WG, **A)
     # variant table: Yelp18 (d128, N64) -> 32 lanes/row, 4 groups x 8 waves; synthetic-HBM (d256, N100) -> 13 groups x 8 waves (4 % capacity slack)
     y = abi.plan(emb_dim=128, num_negs=64, num_users=31668, num_items=38048, train_size=1237259)
-    # 65 rows per interaction: 0.45 in-flight touches per item row with the late re-read write-back
-    # (0.45 * 38048 / 65 = 263 streams, rounded down to one workgroup per compute unit)
-    assert y["cap_items"] == int(0.45 * 38048 / 65) == 263
-    assert (y["lanes_per_row"], y["groups_per_wave"], y["waves_per_workgroup"], y["streams"]) == (32, 4, 8, 256)
+    # 65 rows per interaction: 0.45 in-flight touches per item row with the late re-read write-back (263 streams) and at
+    # least 5600 interactions of the epoch per stream (220 streams)
+    assert y["cap_items"] == int(0.45 * 38048 / 65) == 263 and y["cap_users"] == 1237259 // 5600 == 220
+    assert (y["lanes_per_row"], y["groups_per_wave"], y["waves_per_workgroup"], y["streams"]) == (32, 4, 8, 220)
+    assert abi.plan(emb_dim=128, num_negs=64, num_users=29858, num_items=40981, train_size=810128)["streams"] == 144
     assert y["update_mode"] == "REREAD_POS" and y["update_bits"] == 0x1C
     # ... without device-coherent row traffic there is neither a fresh value to re-read nor an atomic: the reference's
     # literal overwrite, which stays at a worker count the reference itself could have

@@ -26,6 +26,7 @@ ap.add_argument("--seeds", type=str, default="2022")
 ap.add_argument("--clusters", type=int, default=0)
 ap.add_argument("--lr", type=float, default=0.01)
 ap.add_argument("--zipf", type=float, default=1.0, help="item popularity exponent of the synthetic graph")
+ap.add_argument("--interactions", type=int, default=0, help="override the shape's number of train interactions")
 ap.add_argument("--in-cluster", type=float, default=0.8)
 ap.add_argument("--oracle-seeds", type=str, default="", help="seeds the oracle runs for (default: every seed)")
 ap.add_argument("--agg", action="store_true", help="behaviour aggregation (ACCL) on both sides")
@@ -33,7 +34,11 @@ ap.add_argument("--tile", action="store_true", help="random-tile negative sample
                 "`sampling` call, random_tile_negative_sampler.cpp:31-45) on both sides")
 args = ap.parse_args()
 
-g, d, N = synthetic.make_named(args.shape, scale=args.scale, n_clusters=args.clusters, zipf_s=args.zipf, in_cluster=args.in_cluster)
+if args.interactions:
+    _U, _I, _T, d, N = synthetic.SHAPES[args.shape]
+    g = synthetic.make_graph(_U, _I, args.interactions, seed=2022, n_clusters=args.clusters, zipf_s=args.zipf, in_cluster=args.in_cluster)
+else:
+    g, d, N = synthetic.make_named(args.shape, scale=args.scale, n_clusters=args.clusters, zipf_s=args.zipf, in_cluster=args.in_cluster)
 _pop = np.bincount(g.train_items, minlength=g.num_items)
 print(f"hottest item share of positives {_pop.max() / g.train_items.size:.4f}")
 test_dic = {}
