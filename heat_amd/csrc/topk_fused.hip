@@ -290,11 +290,17 @@ template <int CAP> __global__ __launch_bounds__(256, 2) void topk_fused_kernel(F
                 __syncthreads();
                 // this slot's next slab: two slabs further in this tile, else the same slot of the next tile
                 const uint32_t nk = ks + 2u * (uint32_t)KS;
+#ifndef TOPK_ABLATE_LOADS
                 if (nk < d) load_slab(p, u0, i0, nk, sr, sc, ring[slot]);
                 else if (tile + 1 < t_end && (uint32_t)(slot * KS) < d) load_slab(p, u0, i0 + TI, slot * KS, sr, sc, ring[slot]);
+#endif
                 const int kmax = (d - ks) < (uint32_t)KS ? (int)(d - ks) : KS;   // emb_dim % 4 == 0: always even
+#ifndef TOPK_ABLATE_MFMA
                 if (kmax == KS) tile_slab_mfma<true>(s, KS / 2, wu, wi, n, h, acc0, acc1);
                 else tile_slab_mfma<false>(s, kmax / 2, wu, wi, n, h, acc0, acc1);
+#else
+                acc0[0] += s.a[0][wu * 32 + n][h] * (float)kmax; acc1[0] += s.b[0][wi * 64 + n][h];
+#endif
             }
         }
         __syncthreads(); // mbits of this tile visible; LDS slabs free
@@ -317,6 +323,9 @@ template <int CAP> __global__ __launch_bounds__(256, 2) void topk_fused_kernel(F
             }
         }
         cand &= ulive & ((it0 < p.num_items ? 0x55555555u : 0u) | (it1 < p.num_items ? 0xAAAAAAAAu : 0u));
+#ifdef TOPK_ABLATE_SELECT
+        if (acc0[0] != 12345.678f) cand = 0u;     // timing experiment: scores are produced, nothing is ranked
+#endif
         // (2) the rare part: a train item scores -inf (metrics.py:24) and is queued only while its user's list is not full
         if (__ballot(cand != 0u) != 0ull)
         {
