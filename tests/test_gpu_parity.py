@@ -406,8 +406,9 @@ def test_recall_ndcg_parity_yelp18_config():
 
 def test_recall_ndcg_parity_gowalla_config():
     """Full-size Gowalla shape at this fork's Gowalla yaml (d=128, 64 negatives, clip_val 0.1, 8 epochs;
-    Gowalla/MF_CCL/configs/config0.yaml:8-28), clustered graph, same criterion as the Yelp18 config."""
-    gpu, ora, name = _statistical_parity("gowalla", n_clusters=64, epochs=8, clip=0.1, seeds=(1, 2, 3, 4))
+    Gowalla/MF_CCL/configs/config0.yaml:8-28), clustered graph, same criterion as the Yelp18 config.  Single runs scatter
+    more here than at Yelp18 shape (oracle Recall@20 0.0311 ... 0.0329 over four seeds): six seeds per side."""
+    gpu, ora, name = _statistical_parity("gowalla", n_clusters=64, epochs=8, clip=0.1, seeds=(1, 2, 3, 4, 5, 6))
     assert "upd=0x1c" in name and "streams=144" in name, name
     assert abs(gpu[:, 0].mean() - ora[:, 0].mean()) <= 1e-3, (gpu, ora)
     assert abs(gpu[:, 1].mean() - ora[:, 1].mean()) <= 1e-3, (gpu, ora)
