@@ -226,7 +226,7 @@ __global__ __launch_bounds__(64 * NW) void ccl_train_kernel(TrainArgs a)
     static_assert(!AGG || NW == 1, "behaviour aggregation is built for single-wave workgroups");
     const bool neg_w_atomic = (a.upd_bits & 1u) != 0u, neg_g_atomic = (a.upd_bits & 2u) != 0u;
     const bool pos_w_atomic = (a.upd_bits & 4u) != 0u, pos_g_atomic = (a.upd_bits & 8u) != 0u;
-    const bool any_atomic = a.upd_bits != 0u;
+    const bool any_atomic = (a.upd_bits & 0xFu) != 0u;
     constexpr int R = 64 / LPR;            // rows fetched by one wave instruction
     constexpr int WCAP = NGW * R;          // negative slots held by one wave
     constexpr int NIDV = (WCAP + 63) / 64; // id registers per lane (lane k, register v: slot wave_base + v*64 + k)

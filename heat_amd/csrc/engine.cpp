@@ -344,7 +344,7 @@ TrainArgs make_args(const heat_cf_engine* e, uint64_t begin, uint64_t end)
     a.tile_size = e->cfg.neg_sampler == 1 ? (uint32_t)e->cfg.tile_size : 0u;
     a.refresh_interval = (uint32_t)std::max<uint64_t>(1, e->cfg.refresh_interval);
     a.upd_bits = (uint32_t)e->upd;
-    a.align_cap = e->upd == 0 ? 4096u : 0u; // overwrite mode keeps a user's run inside one stream; atomic modes need not
+    a.align_cap = (e->upd & 0xF) == 0 ? 4096u : 0u; // overwrite mode keeps a user's run inside one stream; atomic modes need not
     a.lr = e->lr;
     a.clip = e->cfg.clip_val;
     a.key = epoch_key(e->cfg.seed, e->epoch);
