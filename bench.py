@@ -158,6 +158,37 @@ class stdout_to_stderr:
         os.close(self.saved)
 
 
+def tile_sampler_leg(clicks_t, n, uw_h, iw_h, dev, stream, U, I, d, N, steps):
+    """the random-tile sampler (neg_sampler 1, tile 512, refresh 8192; its sampling() call) with the tile's
+    weight deltas resident in LDS — the same graph and tables as the headline, another sampling distribution."""
+    import torch
+    from heat_amd import abi
+    user_w = torch.from_numpy(uw_h).to(dev)
+    item_w = torch.from_numpy(iw_h).to(dev)
+    out = {}
+    for name, extra in (("in_lds", 0), ("in_global_memory", abi.FLAG_TILE_GLOBAL)):
+        eng = abi.Engine.from_device(clicks_t.data_ptr(), n, user_w.data_ptr(), item_w.data_ptr(), num_users=U, num_items=I,
+                                     emb_dim=d, num_negs=N, stream=stream, keep=(clicks_t, user_w, item_w), seed=2022,
+                                     neg_sampler=1, tile_size=512, refresh_interval=8192, flags=abi.FLAG_SAMPLING_CALL | extra)
+        for k in range(1 + steps):
+            if k == 1:
+                torch.cuda.synchronize()
+                eng.kernel_time(reset=True)
+                t0 = time.perf_counter()
+            eng.begin_epoch()
+            eng.train_range(0, n, want_loss=False)
+            eng.end_epoch()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        kernel_ms, launches = eng.kernel_time()
+        out[name] = {"value": n * steps / dt, "unit": "samples/s", "kernel_ms_per_launch": kernel_ms / max(launches, 1),
+                     "kernel": eng.kernel_name}
+        eng.close()
+    out["note"] = ("random-tile sampler (tile 512, refresh 8192, sampling() call): tile deltas resident in LDS (12 streams per "
+                   "workgroup, flushed by float atomics at the end of the launch) vs every step written to the table")
+    return out
+
+
 def host_mode_leg(graph, d, N, steps, pinned):
     """The same epoch through the reference's own boundary: `cf_c` objects on host numpy buffers, trained in place and
     written back after every epoch (init_modules.cpp:79-81 contract).  pinned=True: the weight arrays live in page-locked
@@ -393,6 +424,8 @@ def main():
             out["host_mode_note"] = ("same epoch through cf_c on host numpy buffers, weights written back after every epoch "
                                      "(PCIe-inclusive; never `value`): page-locked arrays as heat_amd.cf.frontend allocates "
                                      "them / plain pageable numpy arrays")
+            out["tile_sampler"] = tile_sampler_leg(torch.from_numpy(graph.clicks.view(np.int64)).to(dev), T, uw_h, iw_h, dev, stream,
+                                                   U, I, d, N, k)
             out["roofline_hbm_resident"] = hbm_resident_leg(dev, stream, 4_000_000)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(graph, d, N)

@@ -113,7 +113,10 @@ def main(argv=None):
                          use_aggregator=bool(model_config.get('use_aggregator', False)),
                          # optional extension keys (absent from the reference's yaml): 0 = the engine's own choice
                          num_streams=int(model_config.get('num_streams', 0)),
-                         update_mode=int(model_config.get('update_mode', 0)))
+                         update_mode=int(model_config.get('update_mode', 0)),
+                         # `sampling_call: true` = the loop's alternative sampler call (train/engine.cpp:333): the only one in
+                         # which neg_sampler 1 draws from its tile (random_tile_negative_sampler.cpp:23-45 vs :47-57)
+                         flags=4 if model_config.get('sampling_call', False) else 0)
     print('--- Start loading data ---')
     if args.synthetic:
         graph, _, _ = synthetic.make_named(args.synthetic, seed=seed, scale=args.scale)

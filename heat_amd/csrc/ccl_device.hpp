@@ -143,13 +143,20 @@ __device__ __forceinline__ uint32_t uniform_item(uint64_t draw, uint32_t num_ite
 // is itself a Philox draw from a separate counter domain (bit 63 of the index set), so no tile is ever stored:
 //   j  = mulhi64(philox(slot, sample_base + idx), tile_size)
 //   id = mulhi64(philox(j, 2^63 | stream << 32 | tile_epoch), num_items)
+// id of tile entry j of (tile owner, tile_epoch)
+__device__ __forceinline__ uint32_t tile_entry(uint32_t j, uint64_t key, uint32_t owner, uint64_t tile_epoch, uint32_t num_items)
+{
+    const uint64_t tidx = (1ull << 63) | ((uint64_t)owner << 32) | (tile_epoch & 0xFFFFFFFFull);
+    return uniform_item(philox_draw64(j, tidx, key), num_items);
+}
+
 __device__ __forceinline__ uint32_t tile_item(uint32_t slot, uint64_t idx, uint64_t key, uint32_t stream, uint64_t call,
-                                              uint32_t tile_size, uint32_t refresh_interval, uint32_t num_items)
+                                              uint32_t tile_size, uint32_t refresh_interval, uint32_t num_items,
+                                              uint32_t* tile_index = nullptr)
 {
     const uint32_t j = (uint32_t)__umul64hi(philox_draw64(slot, idx, key), (uint64_t)tile_size);
-    const uint64_t tile_epoch = call / (uint64_t)refresh_interval;
-    const uint64_t tidx = (1ull << 63) | ((uint64_t)stream << 32) | (tile_epoch & 0xFFFFFFFFull);
-    return uniform_item(philox_draw64(j, tidx, key), num_items);
+    if (tile_index) *tile_index = j;
+    return tile_entry(j, key, stream, call / (uint64_t)refresh_interval, num_items);
 }
 
 } // namespace heatcf

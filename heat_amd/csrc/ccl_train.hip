@@ -220,10 +220,23 @@ __device__ __forceinline__ void flush_user_row(const TrainArgs& a, uint32_t user
 // gradient itself is still the one of the forward pass.  This shrinks the read-modify-write window of a negative row
 // from the whole interaction (gather -> softmax -> sweep) to one memory round trip, i.e. the share of negative updates
 // lost to a concurrent writer by the same factor, without the memory-side atomic rate.
-template <int LPR, int NGW, int AUX, int NW, bool AGG, bool RR = false>
-__global__ __launch_bounds__(64 * NW) void ccl_train_kernel(TrainArgs a)
+//
+// TS > 1 ("tile-resident", SURVEY 8f row 2: the random-tile sampler with its tile held in LDS): TS single-wave streams
+// form one workgroup and share ONE tile of `tile_size` item rows for the whole launch
+// (negative_samplers/random_tile_negative_sampler.cpp:22-45 keeps a tile per worker for refresh_interval calls).  What
+// lives in LDS is the tile's accumulated weight DELTA, D[tile_size][emb_dim] fp32 (512 x 64 x 4 B = 128 KB of the 160 KB):
+//   forward  : a negative row is W_global[id] + D[j]   (j = its tile index);
+//   backward : the clipped-SGD step of a negative row is added to D[j] (a 16-byte LDS read-modify-write per lane) instead
+//              of being stored to W; G is read-modify-written in global memory as always;
+//   flush    : at the end of the launch (= tile refresh; the engine only selects this kernel when a stream makes fewer
+//              than refresh_interval calls per launch) every D row is added to its W row by 256-byte float atomics.
+// Nothing is lost and no base copy is needed (there is no room for one); other workgroups see this tile's negative updates
+// one launch late.  A negative row then costs 3 row transfers instead of 4 (the W store stays on chip).
+template <int LPR, int NGW, int AUX, int NW, bool AGG, bool RR = false, int TS = 1>
+__global__ __launch_bounds__(64 * NW * TS) void ccl_train_kernel(TrainArgs a)
 {
     static_assert(!AGG || NW == 1, "behaviour aggregation is built for single-wave workgroups");
+    static_assert(TS == 1 || (NW == 1 && !AGG && !RR), "the tile-resident mode is built for plain single-wave variants");
     const bool neg_w_atomic = (a.upd_bits & 1u) != 0u, neg_g_atomic = (a.upd_bits & 2u) != 0u;
     const bool pos_w_atomic = (a.upd_bits & 4u) != 0u, pos_g_atomic = (a.upd_bits & 8u) != 0u;
     const bool any_atomic = (a.upd_bits & 0xFu) != 0u;
@@ -239,6 +252,8 @@ __global__ __launch_bounds__(64 * NW) void ccl_train_kernel(TrainArgs a)
     constexpr int GPF = RR ? (NGW < 2 ? NGW : 2) : (NW > 1 ? (NGW < 16 ? NGW : 16) : (NGW < 4 ? NGW : 4));
     const int lane = (int)(threadIdx.x & 63u);
     const int wave = NW == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int swave = TS == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // stream inside the workgroup
+    const uint32_t stream_id = blockIdx.x * (uint32_t)TS + (uint32_t)swave;
     const uint32_t wave_base = (uint32_t)(wave * WCAP);
     const int sub = lane & (LPR - 1);      // 16-byte column of the row
     const int rr = lane / LPR;             // which of the R rows of a group this lane serves
@@ -252,7 +267,8 @@ __global__ __launch_bounds__(64 * NW) void ccl_train_kernel(TrainArgs a)
     const __amdgpu_buffer_rsrc_t item_w = make_rsrc(a.item_w, a.item_bytes);
     const __amdgpu_buffer_rsrc_t item_g = make_rsrc(a.item_g, a.item_bytes);
 
-    uint64_t first = a.begin + (uint64_t)blockIdx.x * a.per_block;
+    uint64_t first = a.begin + (uint64_t)stream_id * a.per_block;
+    if (first > a.end) first = a.end;
     uint64_t last = first + a.per_block;
     if (last > a.end) last = a.end;
     if (a.align_cap != 0u)
@@ -260,11 +276,11 @@ __global__ __launch_bounds__(64 * NW) void ccl_train_kernel(TrainArgs a)
         first = align_to_user_run(a.clicks, first, a.begin, a.end, a.align_cap, lane);
         last = align_to_user_run(a.clicks, last, a.begin, a.end, a.align_cap, lane);
     }
-    __shared__ __attribute__((aligned(16))) float tile_all[NW * 256]; // per-wave transpose tile for the atomics
+    __shared__ __attribute__((aligned(16))) float tile_all[NW * TS * 256]; // per-wave transpose tile for the atomics
     __shared__ float sh_stat[NW > 1 ? NW * 2 : 1];                    // per-wave (max, sum of exp)
     __shared__ __attribute__((aligned(16))) float sh_gu[NW > 1 ? NW * 64 * 4 : 4]; // per-wave user-gradient partials
     __shared__ float sh_slg[NW > 1 ? NW : 1];
-    float* tile = tile_all + wave * 256;
+    float* tile = tile_all + (wave + swave) * 256;
     // aggregation state (dynamic LDS: W0 copy [D*D] | pair ring [32][2][DP] | means [DP]); D = emb_dim, DP = 4*LPR
     extern __shared__ __attribute__((aligned(16))) float agg_lds[];
     constexpr int DP = 4 * LPR;
@@ -280,6 +296,17 @@ __global__ __launch_bounds__(64 * NW) void ccl_train_kernel(TrainArgs a)
     {
         for (int t = lane; t < D * D / 4; t += 64)   // W0 is [D,D] row-major, D % 4 == 0
             reinterpret_cast<f32x4*>(agg_w0)[t] = buf_load<AUX>(make_rsrc(a.w0, (uint32_t)(D * D * 4)), (uint32_t)t * 16u);
+    }
+    float* tile_delta = agg_lds;            // TS > 1: D[tile_size][emb_dim]
+    uint32_t nidj[NIDV];                    // TS > 1: tile index of each negative slot
+    uint32_t raw_batch_j = 0u;
+#pragma unroll
+    for (int v = 0; v < NIDV; ++v) nidj[v] = 0u;
+    if constexpr (TS > 1)
+    {
+        for (uint32_t t = threadIdx.x; t < a.tile_size * (uint32_t)D / 4u; t += 64u * TS)
+            reinterpret_cast<f32x4*>(tile_delta)[t] = f32x4{0, 0, 0, 0};
+        __syncthreads();
     }
     // A user run cut by a stream boundary is also being updated by the neighbouring stream: its row is then written
     // back as an atomic delta (nothing lost); a run owned entirely by this stream is written back with plain stores.
@@ -338,11 +365,12 @@ __global__ __launch_bounds__(64 * NW) void ccl_train_kernel(TrainArgs a)
                     const uint64_t bidx = a.sample_base + idx + (uint64_t)(lane >> 4);
                     if (a.tile_size != 0u && a.sampling_call)
                         raw_batch = tile_item((uint32_t)(lane & 15), bidx, a.key, blockIdx.x, idx + (uint64_t)(lane >> 4) - first,
-                                              a.tile_size, a.refresh_interval, a.num_items);
+                                              a.tile_size, a.refresh_interval, a.num_items, &raw_batch_j);
                     else
                         raw_batch = uniform_item(philox_draw64((uint32_t)(lane & 15), bidx, a.key), a.num_items);
                 }
                 uint32_t id = lane_get(raw_batch, ((j & 3) << 4) | (lane & 15));
+                if (TS > 1) nidj[0] = lane_get(raw_batch_j, ((j & 3) << 4) | (lane & 15));
                 if (!a.sampling_call && id == pos) id = nid[0];      // ignore_pos_sampling: keep the previous id
                 nid[0] = id;
                 if (a.neg_out != nullptr && (uint32_t)lane < N) a.neg_out[(idx - a.neg_out_base) * N + (uint32_t)lane] = id;
@@ -387,7 +415,7 @@ __global__ __launch_bounds__(64 * NW) void ccl_train_kernel(TrainArgs a)
                     // (random_tile_negative_sampler.cpp:47-57), only its sampling() does (:23-45)
                     if (a.tile_size != 0u && a.sampling_call)
                         id = tile_item(slot, a.sample_base + idx, a.key, blockIdx.x, idx - first, a.tile_size,
-                                       a.refresh_interval, a.num_items);
+                                       a.refresh_interval, a.num_items, &nidj[v]);
                     else
                         id = uniform_item(philox_draw64(slot, a.sample_base + idx, a.key), a.num_items);
                     // ignore_pos_sampling (uniform_random_negative_sampler.cpp:26-36): a draw equal to the
@@ -468,6 +496,7 @@ __global__ __launch_bounds__(64 * NW) void ccl_train_kernel(TrainArgs a)
 
             f32x4 n4[NGW];
             uint32_t noff[NGW];
+            uint32_t doff[TS > 1 ? NGW : 1];                 // TS > 1: float offset of the row's delta in LDS (or ~0)
 #pragma unroll
             for (int g = 0; g < NGW; ++g)
             {
@@ -491,6 +520,18 @@ __global__ __launch_bounds__(64 * NW) void ccl_train_kernel(TrainArgs a)
                 const bool valid = wave_base + (uint32_t)wk < N;
                 noff[g] = (valid && col_ok) ? id * a.row_bytes + col_off : OOB_OFF;
                 n4[g] = buf_load<AUX>(item_w, noff[g]);
+                if constexpr (TS > 1)
+                {
+                    const uint32_t jrow = lane_get(nidj[(g * R) / 64], wk & 63);
+                    doff[g] = (valid && col_ok) ? jrow * a.emb_dim + (uint32_t)sub * 4u : 0xFFFFFFFFu;
+                }
+            }
+            if constexpr (TS > 1)
+            {
+                // the row as this workgroup sees it: global weights + the tile's accumulated delta
+#pragma unroll
+                for (int g = 0; g < NGW; ++g)
+                    if (doff[g] != 0xFFFFFFFFu) n4[g] += *reinterpret_cast<const f32x4*>(tile_delta + doff[g]);
             }
 
             // ---- duplicate negatives inside one interaction (rare): multiplicity per slot ------------------
@@ -694,7 +735,20 @@ __global__ __launch_bounds__(64 * NW) void ccl_train_kernel(TrainArgs a)
                 // a negative that equals the positive is not written: the positive's write-back comes last in the
                 // reference (matrix_factorization.cpp:171-174) and overwrites it
                 if (woff != OOB_OFF && woff - col_off == pos * a.row_bytes) woff = OOB_OFF;
-                if (!neg_w_atomic && !neg_g_atomic)
+                if constexpr (TS > 1)
+                {
+                    // sgd.cpp:23 as a delta: the step goes into the tile's LDS accumulator, re-read just before (one 16-byte
+                    // read-modify-write per lane; four scalar LDS float atomics per lane ran 2x slower for the whole epoch,
+                    // and two of the TS streams meeting in one row inside these few cycles is rarer than the collisions the
+                    // plain stores of the table path accept)
+                    if (woff != OOB_OFF)
+                    {
+                        f32x4* dst = reinterpret_cast<f32x4*>(tile_delta + doff[g]);
+                        *dst = *dst - lr * gn;
+                    }
+                    buf_store<AUX>(item_g, woff, gn);                           // :149
+                }
+                else if (!neg_w_atomic && !neg_g_atomic)
                 {
                     buf_store<AUX>(item_w, woff, w_base - lr * gn);             // sgd.cpp:23, :148
                     buf_store<AUX>(item_g, woff, gn);                           // :149
@@ -793,7 +847,18 @@ __global__ __launch_bounds__(64 * NW) void ccl_train_kernel(TrainArgs a)
     if (cur_user != 0xFFFFFFFFu && wave == 0)                                              // :171-172
         flush_user_row<LPR, AUX>(a, cur_user, cur_user == cut_head_user || cur_user == cut_tail_user, u4, gu4, u4_in,
                                  gu4_in, tile, lane, rr, col_ok, col_off);
-    if (wave == 0 && lane == 0) a.loss_part[blockIdx.x] = loss_acc;
+    if (wave == 0 && lane == 0) a.loss_part[stream_id] = loss_acc;
+    if constexpr (TS > 1)
+    {
+        // tile refresh = end of the launch: every accumulated delta row goes to its W row, 256 contiguous bytes per atomic
+        __syncthreads();
+        for (uint32_t jrow = (uint32_t)swave; jrow < a.tile_size; jrow += (uint32_t)TS)
+        {
+            const uint32_t id = tile_entry(jrow, a.key, blockIdx.x, 0ull, a.num_items);
+            for (uint32_t c = (uint32_t)lane; c < a.emb_dim; c += 64u)
+                __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(tile_delta[jrow * a.emb_dim + c], item_w, (int)(id * a.row_bytes + c * 4u), 0, 0);
+        }
+    }
 }
 
 // Deterministic fixed-order reduction of the per-stream loss partials (fp64), accumulated into *out.
@@ -900,6 +965,25 @@ static hipError_t launch_variant(const TrainArgs& a, uint32_t grid, int aux, hip
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
             hipLaunchKernelGGL(kern, dim3(grid), dim3(64), lds, s, a);
+            return hipGetLastError();
+        }
+        else
+        {
+            return hipErrorInvalidValue;
+        }
+    }
+    if (a.tile_streams > 1u)
+    {
+        if constexpr (NW == 1 && LPR <= 16 && NGW <= 4)
+        {
+            if (aux != AUX_SC1 || a.tile_streams != (uint32_t)TILE_STREAMS || a.tile_size == 0u || !a.sampling_call || a.exact_order ||
+                (a.upd_bits & 0x3Fu) != 0xCu)
+                return hipErrorInvalidValue;
+            const size_t lds = (size_t)a.tile_size * a.emb_dim * sizeof(float);
+            auto kern = ccl_train_kernel<LPR, NGW, AUX_SC1, 1, false, false, TILE_STREAMS>;
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * TILE_STREAMS), lds, s, a);
             return hipGetLastError();
         }
         else

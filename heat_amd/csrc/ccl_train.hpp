@@ -21,6 +21,7 @@ struct TrainArgs
     uint32_t     sampling_call;
     uint32_t     exact_order; // serial/parity mode: order cross-wave row writes before the next gather
     uint32_t     tile_size;  // 0: uniform sampler; >0: random-tile sampler (used by the sampling() call only)
+    uint32_t     tile_streams; // > 1: tile-resident kernel — this many single-wave streams per workgroup share one tile in LDS
     uint32_t     refresh_interval;
     uint32_t     upd_bits;   // bit0 neg W atomic, bit1 neg G atomic, bit2 pos W atomic, bit3 pos G atomic
     uint32_t     align_cap;  // how far a stream boundary may move forward to the next user-run start
@@ -40,6 +41,9 @@ struct TrainArgs
     float*          w0;       // [emb_dim, emb_dim] shared aggregator weights
     float           agg_lr;   // frozen at the CONFIG learning rate (behavior_aggregators.cpp:38)
 };
+
+// streams per workgroup of the tile-resident kernel (3 waves per SIMD; 12 KB of transpose tiles beside the 128 KB tile)
+constexpr int TILE_STREAMS = 12;
 
 // per-epoch sampler key: (seed, epoch) -> 64-bit Philox key (= the `seed` argument of hiprand_init)
 inline uint64_t epoch_key(uint64_t seed, uint64_t epoch) { return seed + 0x9E3779B97F4A7C15ull * (epoch + 1ull); }

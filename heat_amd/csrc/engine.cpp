@@ -84,6 +84,7 @@ struct heat_cf_engine
     int      lpr = 0, ng = 0, nw = 1, aux = 0, upd = 0;
     uint32_t cu_count = 256;
     uint32_t auto_streams = 1;
+    bool     tile_resident = false; // random-tile sampler with the tile's weight deltas held in LDS (ccl_train.hip, TS > 1)
     char     kname[96] = {0};
     // timing
     std::vector<EventPair> ev_free, ev_pending;
@@ -259,8 +260,14 @@ int common_init(heat_cf_engine* e, const heat_cf_config* cfg, uint64_t data_rows
     if (prc) return prc;
     e->auto_streams = plan.streams;
     e->upd = (int)plan.upd_bits;
-    std::snprintf(e->kname, sizeof(e->kname), "ccl_train_kernel<%d,%d,%d,%d>/upd=0x%x/streams=%u", e->lpr, e->ng, e->aux, e->nw,
-                  (unsigned)e->upd, (unsigned)plan.streams);
+    // with the random-tile sampler (its sampling() call) the tile lives in LDS when it fits: 12 single-wave
+    // streams per workgroup share tile_size x emb_dim fp32 of accumulated weight deltas (<= 128 KB)
+    e->tile_resident = cfg->neg_sampler == 1 && (cfg->flags & HEAT_CF_FLAG_SAMPLING_CALL) &&
+                       !(cfg->flags & (HEAT_CF_FLAG_SERIAL | HEAT_CF_FLAG_TILE_GLOBAL)) && e->nw == 1 && e->lpr <= 16 && e->ng <= 4 &&
+                       !cfg->use_aggregator && plan.upd_bits == 0xCu && e->aux == 16 && cfg->tile_size <= 0xFFFFFFFFull &&
+                       cfg->tile_size * cfg->emb_dim * sizeof(float) <= 128u * 1024u;
+    std::snprintf(e->kname, sizeof(e->kname), "ccl_train_kernel<%d,%d,%d,%d>/upd=0x%x/streams=%u%s", e->lpr, e->ng, e->aux, e->nw,
+                  (unsigned)e->upd, (unsigned)plan.streams, e->tile_resident ? "/tile-in-lds" : "");
     HIP_TRY(hipMalloc(&e->d_sums, 2 * sizeof(double)));
     HIP_TRY(hipMemsetAsync(e->d_sums, 0, 2 * sizeof(double), e->stream));
     HIP_TRY(hipMalloc(&e->d_stats, 4 * sizeof(uint32_t)));
@@ -631,10 +638,20 @@ int heat_cf_train_range(heat_cf_engine* e, uint64_t begin, uint64_t end, const u
     uint64_t per_block = 0;
     uint32_t grid = 0;
     geometry(e, n, &per_block, &grid);
-    int rc = ensure_loss_part(e, grid);
+    // tile-resident kernel: 12 streams per workgroup; the tile must live for the whole launch (a stream makes per_block
+    // calls) and the sampler must be the engine's own
+    const bool resident = e->tile_resident && !neg_ids && per_block <= std::max<uint64_t>(1, e->cfg.refresh_interval);
+    uint32_t launch_grid = grid, loss_slots = grid;
+    if (resident)
+    {
+        launch_grid = (grid + (uint32_t)TILE_STREAMS - 1) / (uint32_t)TILE_STREAMS;
+        loss_slots = launch_grid * (uint32_t)TILE_STREAMS;
+    }
+    int rc = ensure_loss_part(e, loss_slots);
     if (rc) return rc;
     TrainArgs a = make_args(e, begin, end);
     a.per_block = per_block;
+    a.tile_streams = resident ? (uint32_t)TILE_STREAMS : 0u;
     if (neg_ids)
     {
         const size_t cnt = (size_t)n * e->cfg.num_negs;
@@ -661,13 +678,14 @@ int heat_cf_train_range(heat_cf_engine* e, uint64_t begin, uint64_t end, const u
     rc = get_events(e, &ev);
     if (rc) return rc;
     HIP_TRY(hipEventRecord(ev.a, e->stream));
-    HIP_TRY(launch_train(a, e->lpr, e->ng, e->nw, grid, e->aux, e->stream));
+    a.loss_part = e->d_loss_part;   // (re)allocated above
+    HIP_TRY(launch_train(a, e->lpr, e->ng, e->nw, launch_grid, e->aux, e->stream));
     HIP_TRY(hipEventRecord(ev.b, e->stream));
     e->ev_pending.push_back(ev);
     e->launches += 1;
     HIP_TRY(hipMemsetAsync(e->d_sums + 1, 0, sizeof(double), e->stream));
-    HIP_TRY(launch_loss_reduce(e->d_loss_part, grid, e->d_sums + 1, e->stream));
-    HIP_TRY(launch_loss_reduce(e->d_loss_part, grid, e->d_sums, e->stream));
+    HIP_TRY(launch_loss_reduce(e->d_loss_part, loss_slots, e->d_sums + 1, e->stream));
+    HIP_TRY(launch_loss_reduce(e->d_loss_part, loss_slots, e->d_sums, e->stream));
     if (loss_sum)
     {
         HIP_TRY(hipMemcpyAsync(loss_sum, e->d_sums + 1, sizeof(double), hipMemcpyDeviceToHost, e->stream));

@@ -44,6 +44,9 @@ extern "C" {
 #define HEAT_CF_FLAG_LAZY_SYNC     0x2u /* host mode: do not write weights back after every epoch              */
 #define HEAT_CF_FLAG_NULL_STREAM   0x8u /* device mode with stream == NULL: launch on the legacy default stream instead of
                                            creating a private non-blocking one (callers whose other work is there)   */
+#define HEAT_CF_FLAG_TILE_GLOBAL   0x10u /* random-tile sampler: do NOT hold the tile in LDS (default when it fits: 12 streams per
+                                           workgroup share tile_size x emb_dim fp32 of accumulated weight deltas, flushed to
+                                           the table by float atomics at the end of the launch)                          */
 #define HEAT_CF_FLAG_SAMPLING_CALL 0x4u /* use sampler.sampling() (engine.cpp:333) instead of the live
                                            ignore_pos_sampling() (engine.cpp:332)                              */
 

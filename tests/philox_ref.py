@@ -92,3 +92,11 @@ def tile_negatives(begin, end, num_negs, num_items, key, tile_size, refresh_inte
     tidx = (np.uint64(1) << np.uint64(63)) | (stream << np.uint64(32)) | tile_epoch
     ids = _mulhi64(_draw64(j.astype(np.uint32), tidx, key), num_items)
     return ids.reshape(n, num_negs)
+
+
+def tile_entries(tile_size, num_items, key, owner=0, tile_epoch=0):
+    """item ids of the tile of (owner, tile_epoch): entry j = mulhi64(philox(j, 2^63 | owner << 32 | tile_epoch), num_items)
+    (ccl_device.hpp: tile_entry)."""
+    j = np.arange(tile_size, dtype=np.uint32)
+    tidx = np.full(tile_size, (1 << 63) | (int(owner) << 32) | int(tile_epoch), dtype=np.uint64)
+    return _mulhi64(_draw64(j, tidx, key), num_items)
