@@ -1,2 +1,4 @@
 mkdir -p gpurun_out
-python -m pytest tests/test_gpu_parity.py -x -q -rP -k "tile" > gpurun_out/b14_pytest_tile.txt 2>&1; echo "pytest rc=$?"; grep -v "^$" gpurun_out/b14_pytest_tile.txt | tail -30 | cut -c1-250
+python tests/tools/recall_parity.py --shape yelp18 --epochs 8 --clip 0.1 --clusters 64 --update 0 --streams 0 --seeds 1,2,3,4 --oracle-threads "" > gpurun_out/b16_yelp_gpf4.txt 2>&1
+python tests/tools/recall_parity.py --shape gowalla --epochs 8 --clip 0.1 --clusters 64 --update 0 --streams 0 --seeds 1,2,3,4 --oracle-threads "" > gpurun_out/b16_gowalla_gpf4.txt 2>&1
+grep "^GPU\|Recall\|^  kernel" gpurun_out/b16_yelp_gpf4.txt gpurun_out/b16_gowalla_gpf4.txt | cut -c1-230
