@@ -235,7 +235,6 @@ __device__ __forceinline__ void flush_user_row(const TrainArgs& a, uint32_t user
 template <int LPR, int NGW, int AUX, int NW, bool AGG, bool RR = false, int TS = 1>
 __global__ __launch_bounds__(64 * NW * TS) void ccl_train_kernel(TrainArgs a)
 {
-    static_assert(!AGG || NW == 1, "behaviour aggregation is built for single-wave workgroups");
     static_assert(TS == 1 || (NW == 1 && !AGG && !RR), "the tile-resident mode is built for plain single-wave variants");
     const bool neg_w_atomic = (a.upd_bits & 1u) != 0u, neg_g_atomic = (a.upd_bits & 2u) != 0u;
     const bool pos_w_atomic = (a.upd_bits & 4u) != 0u, pos_g_atomic = (a.upd_bits & 8u) != 0u;
@@ -281,21 +280,27 @@ __global__ __launch_bounds__(64 * NW * TS) void ccl_train_kernel(TrainArgs a)
     __shared__ __attribute__((aligned(16))) float sh_gu[NW > 1 ? NW * 64 * 4 : 4]; // per-wave user-gradient partials
     __shared__ float sh_slg[NW > 1 ? NW : 1];
     float* tile = tile_all + (wave + swave) * 256;
-    // aggregation state (dynamic LDS: W0 copy [D*D] | pair ring [32][2][DP] | means [DP]); D = emb_dim, DP = 4*LPR
+    // aggregation state (dynamic LDS: W0 copy [D*D] (when it fits, a.agg_w0_lds) | pair ring [32][2][DP] | means [DP] |
+    // two cross-wave partial buffers [NW][DP] each (NW > 1)); D = emb_dim, DP = 4*LPR
     extern __shared__ __attribute__((aligned(16))) float agg_lds[];
     constexpr int DP = 4 * LPR;
     const int D = (int)a.emb_dim;
+    const bool w0_in_lds = AGG && a.agg_w0_lds != 0u;
     float* agg_w0 = agg_lds;
-    float* agg_pairs = agg_lds + (AGG ? D * D : 0);
+    float* agg_pairs = agg_lds + (w0_in_lds ? D * D : 0);
     float* agg_means = agg_pairs + (AGG ? 32 * 2 * DP : 0);
+    float* agg_part_h = agg_means + (AGG ? DP : 0);              // per-wave partial history sums
+    float* agg_part_f = agg_part_h + (AGG && NW > 1 ? NW * DP : 0); // per-wave partial products
     uint32_t agg_iter = 0u;                 // behavior_aggregators.cpp:31 (per worker, per epoch)
     uint32_t agg_H = 0u;
-    uint32_t hid[2] = {0u, 0u};             // history ids of the current user: lane l holds his[l], his[64 + l]
+    uint32_t hid[4] = {0u, 0u, 0u, 0u};     // history ids of the current user: lane l holds his[l], his[64 + l], ...
     f32x4 means4 = {0, 0, 0, 0};
-    if (AGG)
+    const __amdgpu_buffer_rsrc_t w0_rsrc = make_rsrc(AGG ? a.w0 : a.item_w, AGG ? (uint32_t)(D * D * 4) : 16u);
+    if (w0_in_lds)
     {
-        for (int t = lane; t < D * D / 4; t += 64)   // W0 is [D,D] row-major, D % 4 == 0
-            reinterpret_cast<f32x4*>(agg_w0)[t] = buf_load<AUX>(make_rsrc(a.w0, (uint32_t)(D * D * 4)), (uint32_t)t * 16u);
+        for (int t = (int)threadIdx.x; t < D * D / 4; t += 64 * NW)   // W0 is [D,D] row-major, D % 4 == 0
+            reinterpret_cast<f32x4*>(agg_w0)[t] = buf_load<AUX>(w0_rsrc, (uint32_t)t * 16u);
+        if (NW > 1) __syncthreads();
     }
     float* tile_delta = agg_lds;            // TS > 1: D[tile_size][emb_dim]
     uint32_t nidj[NIDV];                    // TS > 1: tile index of each negative slot
@@ -443,24 +448,36 @@ __global__ __launch_bounds__(64 * NW * TS) void ccl_train_kernel(TrainArgs a)
                 {
                     agg_H = a.masks[user];                                        // behavior_aggregators.cpp:61-62
                     const uint32_t* hrow = a.his + (size_t)user * a.max_his;       // :60
-                    hid[0] = (uint32_t)lane < agg_H ? hrow[lane] : 0u;
-                    hid[1] = (uint32_t)(64 + lane) < agg_H ? hrow[64 + lane] : 0u;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) hid[q] = (uint32_t)(64 * q + lane) < agg_H ? hrow[64 * q + lane] : 0u;
                 }
             }
             if (AGG)
             {
                 // ---- aggregator forward (behavior_aggregators.cpp:96-122) -----------------------------------------
+                // The H history rows are fetched R per wave instruction, instruction q by wave q % NW; the d x d product
+                // likewise by rows of W0.  With NW > 1 the per-wave partial sums cross through LDS (two barriers) and every
+                // wave adds them in the same order, so the replicated user row stays identical across waves.
+                auto his_id = [&](uint32_t hh) {
+                    uint32_t id = lane_get(hid[0], (int)(hh & 63u));
+#pragma unroll
+                    for (int q = 1; q < 4; ++q)
+                    {
+                        const uint32_t t = lane_get(hid[q], (int)(hh & 63u));
+                        id = (hh >> 6) == (uint32_t)q ? t : id;
+                    }
+                    return id;
+                };
                 f32x4 hs = {0, 0, 0, 0};
-                for (uint32_t h0 = 0; h0 < agg_H; h0 += (uint32_t)(R * 8))
+                const uint32_t n_inst = (agg_H + (uint32_t)R - 1u) / (uint32_t)R;
+                for (uint32_t q0 = (uint32_t)wave; q0 < n_inst; q0 += (uint32_t)(NW * 8))
                 {
                     f32x4 part[8];
 #pragma unroll
                     for (int q = 0; q < 8; ++q)
                     {
-                        const uint32_t hh = h0 + (uint32_t)(q * R + rr);
-                        const uint32_t id0 = lane_get(hid[0], (int)(hh & 63u));
-                        const uint32_t id1 = lane_get(hid[1], (int)(hh & 63u));
-                        const uint32_t id = hh < 64u ? id0 : id1;
+                        const uint32_t hh = (q0 + (uint32_t)(q * NW)) * (uint32_t)R + (uint32_t)rr;
+                        const uint32_t id = his_id(hh);
                         part[q] = buf_load<AUX>(item_w, (hh < agg_H && col_ok) ? id * a.row_bytes + col_off : OOB_OFF);
                     }
 #pragma unroll
@@ -470,19 +487,38 @@ __global__ __launch_bounds__(64 * NW * TS) void ccl_train_kernel(TrainArgs a)
                 hs.y = cross_sum<LPR>(hs.y);
                 hs.z = cross_sum<LPR>(hs.z);
                 hs.w = cross_sum<LPR>(hs.w);
+                if (NW > 1)
+                {
+                    if (rr == 0) *reinterpret_cast<f32x4*>(agg_part_h + wave * DP + sub * 4) = hs;
+                    __syncthreads();                                                  // BA1
+                    hs = f32x4{0, 0, 0, 0};
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) hs += *reinterpret_cast<const f32x4*>(agg_part_h + w * DP + sub * 4);
+                }
                 means4 = hs * (1.0f / (float)agg_H);                                  // :63,105
-                if (rr == 0) *reinterpret_cast<f32x4*>(agg_means + sub * 4) = means4;
+                if (rr == 0) *reinterpret_cast<f32x4*>(agg_means + sub * 4) = means4;   // every wave writes the same values
                 f32x4 f4 = {0, 0, 0, 0};
-                for (int i = rr; i < D; i += R)                                       // :118 f = means (1xD) * W0 (DxD)
+                for (int i = wave * R + rr; i < D; i += NW * R)                       // :118 f = means (1xD) * W0 (DxD)
                 {
                     const float m = agg_means[i];
-                    const f32x4 wrow = col_ok ? *reinterpret_cast<const f32x4*>(agg_w0 + i * D + sub * 4) : f32x4{0, 0, 0, 0};
+                    f32x4 wrow = {0, 0, 0, 0};
+                    if (col_ok)
+                        wrow = w0_in_lds ? *reinterpret_cast<const f32x4*>(agg_w0 + i * D + sub * 4)
+                                         : buf_load<AUX>(w0_rsrc, (uint32_t)(i * D * 4) + col_off);
                     f4 += m * wrow;
                 }
                 f4.x = cross_sum<LPR>(f4.x);
                 f4.y = cross_sum<LPR>(f4.y);
                 f4.z = cross_sum<LPR>(f4.z);
                 f4.w = cross_sum<LPR>(f4.w);
+                if (NW > 1)
+                {
+                    if (rr == 0) *reinterpret_cast<f32x4*>(agg_part_f + wave * DP + sub * 4) = f4;
+                    __syncthreads();                                                  // BA2
+                    f4 = f32x4{0, 0, 0, 0};
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) f4 += *reinterpret_cast<const f32x4*>(agg_part_f + w * DP + sub * 4);
+                }
                 const float gamma = 0.4f, omg = 1.0f - gamma;                          // :37, :122
                 u4 = gamma * u4 + omg * f4;
                 agg_iter += 1u;                                                       // :124
@@ -790,15 +826,15 @@ __global__ __launch_bounds__(64 * NW * TS) void ccl_train_kernel(TrainArgs a)
                 const f32x4 gfull = gu4 + gu_acc;                                    // outs_grad = persistent G + this step
                 const f32x4 fgrad = gfull * omg;                                     // :132
                 const uint32_t slot32 = (agg_iter - 1u) & 31u;
-                if (rr == 0)
+                if (rr == 0 && wave == 0)
                 {
                     *reinterpret_cast<f32x4*>(agg_pairs + (slot32 * 2 + 0) * DP + sub * 4) = means4;
                     *reinterpret_cast<f32x4*>(agg_pairs + (slot32 * 2 + 1) * DP + sub * 4) = fgrad;
                 }
                 if ((agg_iter & 31u) == 0u)                                          // :141 (iteration > 0 holds here)
                 {
-                    const __amdgpu_buffer_rsrc_t w0r = make_rsrc(a.w0, (uint32_t)(D * D * 4));
-                    for (int i0 = 0; i0 < D; i0 += R)                                // R rows of W0 per tile
+                    if (NW > 1) __syncthreads();                                     // the ring is complete and visible
+                    for (int i0 = wave * R; i0 < D; i0 += NW * R)                    // R rows of W0 per tile, rows split over waves
                     {
                         const int i = i0 + rr;
                         f32x4 acc = {0, 0, 0, 0};
@@ -811,11 +847,16 @@ __global__ __launch_bounds__(64 * NW * TS) void ccl_train_kernel(TrainArgs a)
                         const f32x4 delta = -(a.agg_lr * (acc * 0.03125f));          // :143-144 (/32 is exact as *2^-5)
                         const uint32_t off = (i < D && col_ok) ? (uint32_t)(i * D * 4) + col_off : OOB_OFF;
                         const AtomicOffsets ao = atomic_offsets(off, lane);
-                        atomic_add_tile<4>(w0r, ao, delta, tile, lane);
+                        atomic_add_tile<4>(w0_rsrc, ao, delta, tile, lane);
                     }
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // own W0 updates performed ...
-                    for (int t = lane; t < D * D / 4; t += 64)                       // ... then refresh the private copy
-                        reinterpret_cast<f32x4*>(agg_w0)[t] = buf_load<AUX>(w0r, (uint32_t)t * 16u);
+                    if (NW > 1) __syncthreads();                                     // ... by every wave, ring free again
+                    if (w0_in_lds)
+                    {
+                        for (int t = (int)threadIdx.x; t < D * D / 4; t += 64 * NW)  // ... then refresh the private copy
+                            reinterpret_cast<f32x4*>(agg_w0)[t] = buf_load<AUX>(w0_rsrc, (uint32_t)t * 16u);
+                        if (NW > 1) __syncthreads();
+                    }
                 }
                 gu4 = clip4(gfull * gamma, clip);                                    // :148-152 then sgd.cpp:22
             }
@@ -957,20 +998,13 @@ static hipError_t launch_variant(const TrainArgs& a, uint32_t grid, int aux, hip
 {
     if (a.agg)
     {
-        if constexpr (NW == 1)
-        {
-            if (aux != AUX_SC1) return hipErrorInvalidValue;
-            const size_t lds = ((size_t)a.emb_dim * a.emb_dim + 32 * 2 * 4 * LPR + 4 * LPR) * sizeof(float);
-            auto kern = ccl_train_kernel<LPR, NGW, AUX_SC1, 1, true>;
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return e;
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(64), lds, s, a);
-            return hipGetLastError();
-        }
-        else
-        {
-            return hipErrorInvalidValue;
-        }
+        if (aux != AUX_SC1 || (a.upd_bits & 0x10u)) return hipErrorInvalidValue;
+        const size_t lds = agg_lds_bytes(a.emb_dim, LPR, NW, a.agg_w0_lds != 0u);
+        auto kern = ccl_train_kernel<LPR, NGW, AUX_SC1, NW, true>;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), lds, s, a);
+        return hipGetLastError();
     }
     if (a.tile_streams > 1u)
     {
@@ -1086,13 +1120,10 @@ static int occupancy_variant(int aux, bool agg, uint32_t emb_dim)
     hipError_t e = hipErrorInvalidValue;
     if (agg)
     {
-        if constexpr (NW == 1)
-        {
-            const size_t lds = ((size_t)emb_dim * emb_dim + 32 * 2 * 4 * LPR + 4 * LPR) * sizeof(float);
-            auto kern = ccl_train_kernel<LPR, NGW, AUX_SC1, 1, true>;
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, kern, 64, lds);
-        }
+        const size_t lds = agg_lds_bytes(emb_dim, LPR, NW, agg_w0_fits_lds(emb_dim, LPR, NW));
+        auto kern = ccl_train_kernel<LPR, NGW, AUX_SC1, NW, true>;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, kern, 64 * NW, lds);
     }
     else if (aux == AUX_PLAIN)
         e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, ccl_train_kernel<LPR, NGW, AUX_PLAIN, NW, false>, 64 * NW, 0);

@@ -40,10 +40,20 @@ struct TrainArgs
     const uint32_t* masks;    // [num_users] history lengths
     float*          w0;       // [emb_dim, emb_dim] shared aggregator weights
     float           agg_lr;   // frozen at the CONFIG learning rate (behavior_aggregators.cpp:38)
+    uint32_t        agg_w0_lds; // 1: the workgroup keeps a copy of W0 in LDS; 0: W0 rows are read from L2 (emb_dim 256)
 };
 
 // streams per workgroup of the tile-resident kernel (3 waves per SIMD; 12 KB of transpose tiles beside the 128 KB tile)
 constexpr int TILE_STREAMS = 12;
+
+// dynamic LDS of the aggregator kernels: [W0 copy d*d] | pair ring 32 x 2 x DP | means DP | 2 x NW x DP partials (NW > 1)
+inline size_t agg_lds_bytes(uint32_t emb_dim, int lpr, int nw, bool w0_in_lds)
+{
+    const size_t dp = 4u * (size_t)lpr;
+    return ((w0_in_lds ? (size_t)emb_dim * emb_dim : 0) + 32 * 2 * dp + dp + (nw > 1 ? 2 * (size_t)nw * dp : 0)) * sizeof(float);
+}
+// the W0 copy is kept in LDS when everything fits 128 KB (the static LDS of the kernel needs the rest)
+inline bool agg_w0_fits_lds(uint32_t emb_dim, int lpr, int nw) { return agg_lds_bytes(emb_dim, lpr, nw, true) <= 128u * 1024u; }
 
 // per-epoch sampler key: (seed, epoch) -> 64-bit Philox key (= the `seed` argument of hiprand_init)
 inline uint64_t epoch_key(uint64_t seed, uint64_t epoch) { return seed + 0x9E3779B97F4A7C15ull * (epoch + 1ull); }

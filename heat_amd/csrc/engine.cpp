@@ -115,7 +115,10 @@ int validate_cfg(const heat_cf_config* cfg, uint64_t data_rows, int* lpr, int* n
     if (cfg->neg_sampler != 0 && cfg->neg_sampler != 1) return fail(HEAT_CF_EINVAL, "neg_sampler must be 0 or 1");
     if (cfg->neg_sampler == 1 && (cfg->tile_size == 0 || cfg->tile_size > 0xFFFFFFFFull || cfg->refresh_interval == 0))
         return fail(HEAT_CF_EINVAL, "random-tile sampler needs tile_size > 0 and refresh_interval > 0");
-    if (!pick_variant((uint32_t)cfg->emb_dim, (uint32_t)cfg->num_negs, cfg->use_aggregator != 0, lpr, ng, nw))
+    // behaviour aggregation keeps the single-wave variant it was validated with wherever one holds num_negs; the multi-wave
+    // aggregator (history gather and d x d product split over the waves) takes over beyond that
+    if (!(cfg->use_aggregator && pick_variant((uint32_t)cfg->emb_dim, (uint32_t)cfg->num_negs, true, lpr, ng, nw)) &&
+        !pick_variant((uint32_t)cfg->emb_dim, (uint32_t)cfg->num_negs, false, lpr, ng, nw))
         return fail(HEAT_CF_EUNSUP, "no compiled kernel variant for this (emb_dim, num_negs)");
     if (data_rows >= (1ull << 40)) return fail(HEAT_CF_EINVAL, "data_rows too large");
     return HEAT_CF_OK;
@@ -365,6 +368,7 @@ TrainArgs make_args(const heat_cf_engine* e, uint64_t begin, uint64_t end)
     a.masks = e->d_masks;
     a.w0 = e->d_w0;
     a.agg_lr = e->cfg.l_r; // behavior_aggregators.cpp:38: frozen at the config value, not the scheduled lr
+    a.agg_w0_lds = (e->cfg.use_aggregator && agg_w0_fits_lds((uint32_t)e->cfg.emb_dim, e->lpr, e->nw)) ? 1u : 0u;
     return a;
 }
 
@@ -435,10 +439,8 @@ int heat_cf_device_count(void)
 
 static int aggregator_limits(const heat_cf_config* cfg, uint64_t max_his, int lpr, int nw)
 {
-    if (nw != 1) return fail(HEAT_CF_EUNSUP, "behaviour aggregation is built for single-wave variants (num_negs <= 64 rows per wave)");
-    if (max_his == 0 || max_his > 128) return fail(HEAT_CF_EUNSUP, "behaviour aggregation supports 1 <= max_his <= 128");
-    if ((cfg->emb_dim * cfg->emb_dim + 32 * 2 * 4 * (uint64_t)lpr + 4 * (uint64_t)lpr) * 4 > 160 * 1024)
-        return fail(HEAT_CF_EUNSUP, "behaviour aggregation keeps W0 in LDS: emb_dim too large");
+    (void)cfg; (void)lpr; (void)nw;
+    if (max_his == 0 || max_his > 256) return fail(HEAT_CF_EUNSUP, "behaviour aggregation supports 1 <= max_his <= 256");
     return HEAT_CF_OK;
 }
 

@@ -98,10 +98,15 @@ def test_reference_hyperparameters_short_horizon():
     assert_tables_close(ig, io, scale=np.abs(io).max(), rtol=5e-4)
 
 
-@pytest.mark.parametrize("d,N,H", [(64, 16, 100), (64, 4, 7), (128, 16, 40), (32, 8, 100)])
+@pytest.mark.parametrize("d,N,H", [(64, 16, 100), (64, 4, 7), (128, 16, 40), (32, 8, 100),
+                                   (256, 100, 100),   # synthetic 10 M x 1 M config: <64,13> x 8 waves, W0 (256 KB) read from L2
+                                   (128, 100, 60),    # <32,16> x 4 waves, W0 copy in LDS
+                                   (64, 100, 200),    # <16,16> x 2 waves, history longer than 128
+                                   (256, 16, 130)])   # single wave at d = 256: W0 from L2, three id registers
 def test_aggregator_serial_walk_matches_oracle(d, N, H):
     """ACCL mode (behavior_aggregators.cpp:51-153): history mean -> W0 -> in-place blend of the user row, W0 gradient
-    accumulated per worker and applied every 32 calls.  Serial GPU walk vs the oracle, crossing several W0 updates."""
+    accumulated per worker and applied every 32 calls.  Serial GPU walk vs the oracle, crossing several W0 updates;
+    multi-wave workgroups split the history gather and the d x d product over their waves."""
     U, I, T = 12, 400, 200
     rng = np.random.default_rng(d + N + H)
     clicks = np.stack([np.sort(rng.integers(0, U, T)), rng.integers(0, I, T)], axis=1).astype(np.uint64)
@@ -126,6 +131,23 @@ def test_aggregator_serial_walk_matches_oracle(d, N, H):
     assert_tables_close(wg, wo, scale=np.abs(wo).max(), rtol=1e-4)
     assert_tables_close(ug, uo, scale=np.abs(uo).max(), rtol=5e-4)
     assert_tables_close(ig, io, scale=np.abs(io).max(), rtol=5e-4)
+
+
+def test_aggregator_multiwave_hogwild_trains():
+    """The multi-wave aggregator outside the serial mode (several streams, atomics on the shared W0): the synthetic
+    10 M x 1 M config's kernel variant (d = 256, 100 negatives, history 100) on a small graph — finite, and learning."""
+    g = synthetic.make_graph(300, 4000, 12000, seed=3, with_test=False)
+    d, N = 256, 100
+    uw, iw = synthetic.init_embeddings(g.num_users, g.num_items, d, seed=3, std=0.05)
+    his, masks = synthetic.make_history(g, 100, seed=3)
+    w0 = (np.random.default_rng(3).standard_normal((d, d)) * 0.05).astype(np.float32)
+    w0_before = w0.copy()
+    eng = abi.Engine(g.clicks, uw, iw, num_negs=N, his=his, masks=masks, w0=w0, use_aggregator=True, seed=3, num_streams=16)
+    assert "<64,13,16,8>" in eng.kernel_name, eng.kernel_name
+    losses = [eng.train_one_epoch() for _ in range(3)]
+    eng.close()
+    assert np.isfinite(losses).all() and losses[-1] < losses[0], losses
+    assert np.isfinite(uw).all() and np.isfinite(iw).all() and np.isfinite(w0).all() and not np.array_equal(w0, w0_before)
 
 
 def test_aggregator_device_mode_equals_host_mode():

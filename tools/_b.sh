@@ -1,4 +1,2 @@
 mkdir -p gpurun_out
-python tests/tools/recall_parity.py --shape yelp18 --epochs 8 --clip 0.1 --clusters 64 --update 0 --streams 0 --seeds 1,2,3,4 --oracle-threads "" > gpurun_out/b16_yelp_gpf4.txt 2>&1
-python tests/tools/recall_parity.py --shape gowalla --epochs 8 --clip 0.1 --clusters 64 --update 0 --streams 0 --seeds 1,2,3,4 --oracle-threads "" > gpurun_out/b16_gowalla_gpf4.txt 2>&1
-grep "^GPU\|Recall\|^  kernel" gpurun_out/b16_yelp_gpf4.txt gpurun_out/b16_gowalla_gpf4.txt | cut -c1-230
+timeout -k 10 300 python -m pytest tests/test_gpu_parity.py -x -q -k "aggregator or serial_walk or randomized" > gpurun_out/b17_pytest.txt 2>&1; echo "rc=$?"; tail -25 gpurun_out/b17_pytest.txt | cut -c1-220
