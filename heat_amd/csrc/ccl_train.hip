@@ -302,6 +302,15 @@ __global__ __launch_bounds__(64 * NW * TS) void ccl_train_kernel(TrainArgs a)
             reinterpret_cast<f32x4*>(agg_w0)[t] = buf_load<AUX>(w0_rsrc, (uint32_t)t * 16u);
         if (NW > 1) __syncthreads();
     }
+    float* agg_saved = (AGG && a.agg_state) ? a.agg_state + (size_t)stream_id * agg_state_floats(LPR) : nullptr;
+    if (AGG && agg_saved)
+    {
+        // the stream's aggregator as the previous launch of this epoch left it: call counter and the pairs not yet applied
+        agg_iter = reinterpret_cast<const uint32_t*>(agg_saved)[0];
+        const int pending = (int)(agg_iter & 31u) * 2 * DP;
+        for (int t = (int)threadIdx.x; t < pending; t += 64 * NW) agg_pairs[t] = agg_saved[4 + t];
+        if (NW > 1) __syncthreads();
+    }
     float* tile_delta = agg_lds;            // TS > 1: D[tile_size][emb_dim]
     uint32_t nidj[NIDV];                    // TS > 1: tile index of each negative slot
     uint32_t raw_batch_j = 0u;
@@ -888,6 +897,13 @@ __global__ __launch_bounds__(64 * NW * TS) void ccl_train_kernel(TrainArgs a)
     if (cur_user != 0xFFFFFFFFu && wave == 0)                                              // :171-172
         flush_user_row<LPR, AUX>(a, cur_user, cur_user == cut_head_user || cur_user == cut_tail_user, u4, gu4, u4_in,
                                  gu4_in, tile, lane, rr, col_ok, col_off);
+    if (AGG && agg_saved)
+    {
+        if (NW > 1) __syncthreads();
+        const int pending = (int)(agg_iter & 31u) * 2 * DP;
+        for (int t = (int)threadIdx.x; t < pending; t += 64 * NW) agg_saved[4 + t] = agg_pairs[t];
+        if (threadIdx.x == 0) reinterpret_cast<uint32_t*>(agg_saved)[0] = agg_iter;
+    }
     if (wave == 0 && lane == 0) a.loss_part[stream_id] = loss_acc;
     if constexpr (TS > 1)
     {

@@ -41,6 +41,9 @@ struct TrainArgs
     float*          w0;       // [emb_dim, emb_dim] shared aggregator weights
     float           agg_lr;   // frozen at the CONFIG learning rate (behavior_aggregators.cpp:38)
     uint32_t        agg_w0_lds; // 1: the workgroup keeps a copy of W0 in LDS; 0: W0 rows are read from L2 (emb_dim 256)
+    float*          agg_state;  // [streams][agg_state_floats]: call counter + unflushed (means, gradient) pairs of every stream,
+                                // carried from launch to launch within an epoch (behavior_aggregators.cpp:31,139-146: the
+                                // reference's per-worker aggregator lives for the whole epoch)
 };
 
 // streams per workgroup of the tile-resident kernel (3 waves per SIMD; 12 KB of transpose tiles beside the 128 KB tile)
@@ -52,6 +55,8 @@ inline size_t agg_lds_bytes(uint32_t emb_dim, int lpr, int nw, bool w0_in_lds)
     const size_t dp = 4u * (size_t)lpr;
     return ((w0_in_lds ? (size_t)emb_dim * emb_dim : 0) + 32 * 2 * dp + dp + (nw > 1 ? 2 * (size_t)nw * dp : 0)) * sizeof(float);
 }
+// floats of one stream's aggregator state: [0] = call counter (as u32), then the ring of 32 x 2 x DP
+__host__ __device__ inline size_t agg_state_floats(int lpr) { return 4 + 32 * 2 * 4 * (size_t)lpr; }
 // the W0 copy is kept in LDS when everything fits 128 KB (the static LDS of the kernel needs the rest)
 inline bool agg_w0_fits_lds(uint32_t emb_dim, int lpr, int nw) { return agg_lds_bytes(emb_dim, lpr, nw, true) <= 128u * 1024u; }
 

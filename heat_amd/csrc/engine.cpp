@@ -77,6 +77,8 @@ struct heat_cf_engine
     uint32_t* d_ext_negs = nullptr;
     size_t    ext_cap = 0;
     uint32_t* d_stats = nullptr;
+    float*    d_agg_state = nullptr; // per-stream aggregator state carried across the launches of an epoch
+    size_t    agg_state_cap = 0;     // streams it holds
     // scalar state
     float    lr = 0.f;
     uint64_t epoch = 0;
@@ -369,6 +371,7 @@ TrainArgs make_args(const heat_cf_engine* e, uint64_t begin, uint64_t end)
     a.w0 = e->d_w0;
     a.agg_lr = e->cfg.l_r; // behavior_aggregators.cpp:38: frozen at the config value, not the scheduled lr
     a.agg_w0_lds = (e->cfg.use_aggregator && agg_w0_fits_lds((uint32_t)e->cfg.emb_dim, e->lpr, e->nw)) ? 1u : 0u;
+    a.agg_state = e->d_agg_state;
     return a;
 }
 
@@ -393,6 +396,7 @@ void destroy_impl(heat_cf_engine* e)
     (void)hipFree(e->d_sums);
     (void)hipFree(e->d_ext_negs);
     (void)hipFree(e->d_stats);
+    (void)hipFree(e->d_agg_state);
     if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }
@@ -623,6 +627,10 @@ int heat_cf_begin_epoch(heat_cf_engine* e)
         if (e->epoch > 0 && e->epoch % step == 0) e->lr = e->lr * 0.1f;
     }
     HIP_TRY(hipMemsetAsync(e->d_sums, 0, 2 * sizeof(double), e->stream));
+    // the reference builds its per-worker aggregator inside the epoch's parallel region (train/engine.cpp:313-318):
+    // counter and unflushed pairs start from zero every epoch
+    if (e->d_agg_state)
+        HIP_TRY(hipMemsetAsync(e->d_agg_state, 0, e->agg_state_cap * agg_state_floats(e->lpr) * sizeof(float), e->stream));
     return HEAT_CF_OK;
 }
 
@@ -651,6 +659,18 @@ int heat_cf_train_range(heat_cf_engine* e, uint64_t begin, uint64_t end, const u
     }
     int rc = ensure_loss_part(e, loss_slots);
     if (rc) return rc;
+    if (e->cfg.use_aggregator && loss_slots > e->agg_state_cap)
+    {
+        // first launch (or a larger grid than any before): fresh, zeroed state — within an epoch the grid of a later
+        // window is never larger than the first one's
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        if (e->d_agg_state) HIP_TRY(hipFree(e->d_agg_state));
+        e->d_agg_state = nullptr;
+        const size_t bytes = (size_t)loss_slots * agg_state_floats(e->lpr) * sizeof(float);
+        HIP_TRY(hipMalloc(&e->d_agg_state, bytes));
+        HIP_TRY(hipMemsetAsync(e->d_agg_state, 0, bytes, e->stream));
+        e->agg_state_cap = loss_slots;
+    }
     TrainArgs a = make_args(e, begin, end);
     a.per_block = per_block;
     a.tile_streams = resident ? (uint32_t)TILE_STREAMS : 0u;

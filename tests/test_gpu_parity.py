@@ -133,6 +133,36 @@ def test_aggregator_serial_walk_matches_oracle(d, N, H):
     assert_tables_close(ig, io, scale=np.abs(io).max(), rtol=5e-4)
 
 
+@pytest.mark.parametrize("d,N", [(64, 16), (128, 100)])
+def test_aggregator_windows_compose_to_the_whole_range(d, N):
+    """The reference's per-worker aggregator lives for a whole epoch (behavior_aggregators.cpp:31,139-146: call counter and
+    the W0 gradient accumulated since the last multiple of 32).  An epoch cut into windows (multi-GPU exchanges) therefore
+    carries that state from launch to launch: train_range(0,a) + train_range(a,n) must equal train_range(0,n), W0 included,
+    for cuts that are not multiples of 32."""
+    U, I, T, H = 10, 300, 150, 30
+    rng = np.random.default_rng(d + N)
+    clicks = np.stack([np.sort(rng.integers(0, U, T)), rng.integers(0, I, T)], axis=1).astype(np.uint64)
+    uw = (rng.standard_normal((U, d)) * 0.1).astype(np.float32)
+    iw = (rng.standard_normal((I, d)) * 0.1).astype(np.float32)
+    w0 = (rng.standard_normal((d, d)) * 0.1).astype(np.float32)
+    his = rng.integers(0, I, size=(U, H)).astype(np.uint64)
+    masks = rng.integers(1, H + 1, size=(U, 1)).astype(np.uint64)
+    negs = rng.integers(0, I, size=(T, N)).astype(np.uint64)
+    outs = []
+    for cuts in ([0, T], [0, 7, 50, 83, T]):
+        a, b, w = uw.copy(), iw.copy(), w0.copy()
+        eng = abi.Engine(clicks, a, b, num_negs=N, his=his, masks=masks, w0=w, use_aggregator=True, flags=abi.FLAG_SERIAL)
+        eng.begin_epoch()
+        loss = sum(eng.train_range(lo, hi, negs[lo:hi]) for lo, hi in zip(cuts[:-1], cuts[1:]))
+        eng.sync_to_host()
+        eng.close()
+        outs.append((a, b, w, loss))
+    assert not np.array_equal(outs[0][2], w0)                       # W0 was updated (T // 32 = 4 times)
+    for k in range(3):
+        assert np.array_equal(outs[0][k], outs[1][k]), k
+    assert abs(outs[0][3] - outs[1][3]) < 1e-9 * abs(outs[0][3])
+
+
 def test_aggregator_multiwave_hogwild_trains():
     """The multi-wave aggregator outside the serial mode (several streams, atomics on the shared W0): the synthetic
     10 M x 1 M config's kernel variant (d = 256, 100 negatives, history 100) on a small graph — finite, and learning."""
