@@ -217,6 +217,15 @@ int make_plan(const heat_cf_config* cfg, uint64_t data_rows, uint64_t fill, Plan
     return HEAT_CF_OK;
 }
 
+// the random-tile sampler keeps its tile in LDS when this holds (ccl_train.hip, TS > 1)
+bool tile_fits_lds(const heat_cf_config* cfg, const Plan& p)
+{
+    return cfg->neg_sampler == 1 && (cfg->flags & HEAT_CF_FLAG_SAMPLING_CALL) &&
+           !(cfg->flags & (HEAT_CF_FLAG_SERIAL | HEAT_CF_FLAG_TILE_GLOBAL)) && p.nw == 1 && p.lpr <= 16 && p.ng <= 4 &&
+           !cfg->use_aggregator && p.upd_bits == 0xCu && p.coherence == HEAT_CF_COHERENCE_DEVICE &&
+           cfg->tile_size <= 0xFFFFFFFFull && cfg->tile_size * cfg->emb_dim * sizeof(float) <= 128u * 1024u;
+}
+
 int common_init(heat_cf_engine* e, const heat_cf_config* cfg, uint64_t data_rows, void* stream, uint64_t history_rows = 0)
 {
     e->cfg = *cfg;
@@ -267,10 +276,7 @@ int common_init(heat_cf_engine* e, const heat_cf_config* cfg, uint64_t data_rows
     e->upd = (int)plan.upd_bits;
     // with the random-tile sampler (its sampling() call) the tile lives in LDS when it fits: 12 single-wave
     // streams per workgroup share tile_size x emb_dim fp32 of accumulated weight deltas (<= 128 KB)
-    e->tile_resident = cfg->neg_sampler == 1 && (cfg->flags & HEAT_CF_FLAG_SAMPLING_CALL) &&
-                       !(cfg->flags & (HEAT_CF_FLAG_SERIAL | HEAT_CF_FLAG_TILE_GLOBAL)) && e->nw == 1 && e->lpr <= 16 && e->ng <= 4 &&
-                       !cfg->use_aggregator && plan.upd_bits == 0xCu && e->aux == 16 && cfg->tile_size <= 0xFFFFFFFFull &&
-                       cfg->tile_size * cfg->emb_dim * sizeof(float) <= 128u * 1024u;
+    e->tile_resident = tile_fits_lds(cfg, plan);
     std::snprintf(e->kname, sizeof(e->kname), "ccl_train_kernel<%d,%d,%d,%d>/upd=0x%x/streams=%u%s", e->lpr, e->ng, e->aux, e->nw,
                   (unsigned)e->upd, (unsigned)plan.streams, e->tile_resident ? "/tile-in-lds" : "");
     HIP_TRY(hipMalloc(&e->d_sums, 2 * sizeof(double)));
@@ -425,10 +431,10 @@ int heat_cf_plan(const heat_cf_config* cfg, uint64_t data_rows, uint64_t residen
     const int n = std::snprintf(out, (size_t)out_bytes,
                                 "{\"lanes_per_row\": %d, \"groups_per_wave\": %d, \"waves_per_workgroup\": %d, "
                                 "\"negative_capacity\": %d, \"coherence\": \"%s\", \"streams\": %u, \"cap_items\": %u, "
-                                "\"cap_users\": %u, \"update_mode\": \"%s\", \"update_bits\": %u}",
+                                "\"cap_users\": %u, \"update_mode\": \"%s\", \"update_bits\": %u, \"tile_in_lds\": %s}",
                                 p.lpr, p.ng, p.nw, p.ng * (64 / p.lpr) * p.nw,
                                 p.coherence == HEAT_CF_COHERENCE_DEVICE ? "device" : "plain", p.streams, p.cap_items,
-                                p.cap_users, um, p.upd_bits);
+                                p.cap_users, um, p.upd_bits, tile_fits_lds(cfg, p) ? "true" : "false");
     if (n < 0 || (uint64_t)n >= out_bytes) return fail(HEAT_CF_EINVAL, "out buffer too small");
     return HEAT_CF_OK;
 }

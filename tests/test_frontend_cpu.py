@@ -220,6 +220,14 @@ def test_launch_plan_host_logic():
     # a user shard of an 8-GPU job (297 591 interactions): a stream still walks >= 256 interactions
     assert abi.plan(resident_workgroups=256 * 12, **dict(A, num_users=6580, train_size=297591))["streams"] == 297591 // 256 == 1162
     assert p["streams"] == 3017 and p["update_mode"] == "ATOMIC_POS" and p["update_bits"] == 0xC and p["coherence"] == "device"
+    # random-tile sampler (its sampling() call): the tile's weight deltas live in LDS where tile_size x emb_dim x 4 B <= 128 KB
+    T_ = dict(A, neg_sampler=1, tile_size=512, refresh_interval=8192)
+    assert abi.plan(flags=abi.FLAG_SAMPLING_CALL, **T_)["tile_in_lds"] is True
+    assert abi.plan(**T_)["tile_in_lds"] is False                                          # ignore_pos_sampling never uses the tile
+    assert abi.plan(flags=abi.FLAG_SAMPLING_CALL | abi.FLAG_TILE_GLOBAL, **T_)["tile_in_lds"] is False
+    assert abi.plan(flags=abi.FLAG_SAMPLING_CALL, **dict(T_, tile_size=1024))["tile_in_lds"] is False   # 256 KB
+    assert abi.plan(flags=abi.FLAG_SAMPLING_CALL, emb_dim=128, num_negs=64, num_users=31668, num_items=38048,
+                    train_size=1237259, neg_sampler=1, tile_size=512)["tile_in_lds"] is False           # multi-wave variant
     # fewer resident workgroups than the cap: the chip is the limit
     assert abi.plan(resident_workgroups=1024, **A)["streams"] == 1024
     # forcing many streams pushes the expected negative-row collisions past 0.56 -> every item row goes atomic

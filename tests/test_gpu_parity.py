@@ -745,6 +745,58 @@ def test_full_size_properties_amazonbooks_shape():
     eng.close()
 
 
+def test_full_size_properties_synthetic_hbm_shape():
+    """BASELINE.json configs[4] at its full TABLE size (10 M users x 1 M items, d = 256, 100 negatives: 22.5 GB of W and G,
+    far beyond the Infinity Cache; device-resident engine on torch tensors) over a 1 M-interaction sample of its 200 M list
+    (50 000 users spread over the whole table x 20 interactions).  Size-independent properties: (a) lr = 0 leaves both
+    tables bit-identical and the mean loss is that of near-orthogonal rows, log(1 + 100) up to the init's scatter;
+    (b) a real epoch changes exactly the user rows that have interactions, keeps everything finite, and leaves both
+    gradient tables zero (engine.cpp:345-347); (c) the kernel is the 8-wave variant the launch plan picks for this shape."""
+    import torch
+    U, I, _, d, N = synthetic.SHAPES["synthetic_hbm"]
+    T = 1_000_000
+    dev = torch.device("cuda", 0)
+    free, _total = torch.cuda.mem_get_info(dev)
+    if free < 40 * (1 << 30):
+        pytest.skip("needs 40 GB of free device memory")
+    side = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(side):
+        clicks = synthetic.make_clicks_torch(U, I, T, dev, seed=5, per_user=20)
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(5)
+        user_w = torch.empty((U, d), device=dev, dtype=torch.float32).normal_(0.0, 0.01, generator=gen)
+        item_w = torch.empty((I, d), device=dev, dtype=torch.float32).normal_(0.0, 0.01, generator=gen)
+        u0 = user_w.clone()
+        i0 = item_w.clone()
+        common = dict(num_users=U, num_items=I, emb_dim=d, num_negs=N, stream=side.cuda_stream, seed=5,
+                      keep=(clicks, user_w, item_w))
+        eng = abi.Engine.from_device(clicks.data_ptr(), T, user_w.data_ptr(), item_w.data_ptr(), l_r=0.0, **common)
+        assert "<64,13,16,8>" in eng.kernel_name, eng.kernel_name                                      # (c)
+        loss0 = eng.train_one_epoch()
+        side.synchronize()
+        assert torch.equal(user_w, u0) and torch.equal(item_w, i0)                                     # (a)
+        assert abs(loss0 - np.log(1.0 + N)) < 0.5, loss0
+        eng.close()
+        eng = abi.Engine.from_device(clicks.data_ptr(), T, user_w.data_ptr(), item_w.data_ptr(), l_r=0.01, clip_val=1.0, **common)
+        loss1 = eng.train_one_epoch()
+        side.synchronize()
+        assert np.isfinite(loss1) and bool(torch.isfinite(user_w).all()) and bool(torch.isfinite(item_w).all())   # (b)
+        touched = torch.zeros(U, dtype=torch.bool, device=dev)
+        touched[clicks[:, 0]] = True
+        moved = (user_w != u0).any(dim=1)
+        assert bool((moved == touched).all()) and int(touched.sum()) > 40_000
+        assert bool((item_w != i0).any())
+        view = eng.device_view()
+        # the engine's G tables are its own allocations: read through the C ABI, the user side in five 256 MB slabs
+        slab = 250_000
+        for lo in range(0, U, slab * 8):
+            assert not eng.read_device(view.user_g + lo * d * 4, (min(slab, U - lo), d)).any()
+        assert not eng.read_device(view.item_g, (I, d)).any()
+        eng.close()
+    del user_w, item_w, u0, i0, clicks
+    torch.cuda.empty_cache()
+
+
 def test_topk_full_size_properties_amazonbooks_shape():
     """Size-independent properties of the fused top-k at the full AmazonBooks size (52 643 users x 91 599 items, the matrix
     the reference's evaluate0 materialises in 19.3 GB): (a) no train item is ever returned; (b) the ids of a row are

@@ -1,2 +1,2 @@
 mkdir -p gpurun_out
-timeout -k 10 300 python -m pytest tests/test_gpu_parity.py tests/test_distributed_cpu.py -x -q -k "aggregator or distributed_main or two_ranks" > gpurun_out/b19_pytest.txt 2>&1; echo "rc=$?"; tail -25 gpurun_out/b19_pytest.txt | cut -c1-220
+timeout -k 10 400 python -m pytest tests/test_gpu_parity.py -x -q -rP -k "synthetic_hbm or tile" > gpurun_out/b20_pytest.txt 2>&1; echo "rc=$?"; tail -12 gpurun_out/b20_pytest.txt | cut -c1-220
