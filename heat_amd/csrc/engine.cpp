@@ -893,6 +893,7 @@ static int topk_fused(heat_cf_engine* e, uint64_t u_begin, uint64_t u_end, uint3
     const size_t part_elems = (size_t)k * std::max<uint64_t>(panel * topk_fused_splits((uint32_t)panel, (uint32_t)I, slots),
                                                              last * topk_fused_splits((uint32_t)last, (uint32_t)I, slots));
     float*    d_pv = nullptr;
+    float*    d_thr = nullptr;
     uint32_t* d_pi = nullptr;
     uint32_t* d_topk = nullptr;
     uint64_t* d_indptr = nullptr;
@@ -902,6 +903,7 @@ static int topk_fused(heat_cf_engine* e, uint64_t u_begin, uint64_t u_end, uint3
     size_t items_cap = 0, temp_cap = 0;
     std::vector<uint64_t> rel;
     hipError_t err = hipMalloc(&d_pv, part_elems * sizeof(float));
+    if (err == hipSuccess) err = hipMalloc(&d_thr, (size_t)panel * sizeof(float));
     if (err == hipSuccess) err = hipMalloc(&d_pi, part_elems * sizeof(uint32_t));
     if (err == hipSuccess) err = hipMalloc(&d_topk, (size_t)panel * k * sizeof(uint32_t));
     if (err == hipSuccess && mask_indptr) err = hipMalloc(&d_indptr, (panel + 1) * sizeof(uint64_t));
@@ -976,7 +978,7 @@ static int topk_fused(heat_cf_engine* e, uint64_t u_begin, uint64_t u_end, uint3
         ms_check += ms(t0, t1);
         if (err == hipSuccess)
             err = launch_topk_fused(e->d_user_w + ug * d, e->d_item_w, (uint32_t)rows, (uint32_t)I, (uint32_t)d, k,
-                                    mask_indptr ? d_indptr : nullptr, d_items, splits, d_pv, d_pi, d_topk, e->stream);
+                                    mask_indptr ? d_indptr : nullptr, d_items, splits, d_pv, d_pi, d_topk, d_thr, e->stream);
         if (err == hipSuccess)
             err = hipMemcpyAsync(topk + p0 * k, d_topk, (size_t)rows * k * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream);
         if (err == hipSuccess) err = hipStreamSynchronize(e->stream); // rel is reused by the next panel
@@ -984,6 +986,7 @@ static int topk_fused(heat_cf_engine* e, uint64_t u_begin, uint64_t u_end, uint3
     }
     (void)hipStreamSynchronize(e->stream);
     (void)hipFree(d_pv);
+    (void)hipFree(d_thr);
     (void)hipFree(d_pi);
     (void)hipFree(d_topk);
     (void)hipFree(d_indptr);

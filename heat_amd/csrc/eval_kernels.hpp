@@ -21,10 +21,11 @@ hipError_t launch_topk_rows(float* sim, uint32_t rows, uint32_t num_items, uint3
 #define TOPK_FUSED_MAX_SPLITS 16
 // how many item-range splits to run for `rows` users when the chip holds `slots` workgroups at once
 uint32_t topk_fused_splits(uint32_t rows, uint32_t num_items, uint32_t slots);
-// part_v / part_i: scratch [splits, rows, k]; topk: DEVICE [rows, k]; indptr (relative, [rows+1]) / items may be NULL
+// part_v / part_i: scratch [splits, rows, k]; thr_shared: scratch [rows] (threshold exchange between item splits);
+// topk: DEVICE [rows, k]; indptr (relative, [rows+1]) / items may be NULL
 hipError_t launch_topk_fused(const float* user_rows, const float* item_w, uint32_t rows, uint32_t num_items,
                              uint32_t emb_dim, uint32_t k, const uint64_t* indptr, const uint32_t* items, uint32_t splits,
-                             float* part_v, uint32_t* part_i, uint32_t* topk, hipStream_t s);
+                             float* part_v, uint32_t* part_i, uint32_t* topk, float* thr_shared, hipStream_t s);
 // items_out[indptr[r] .. indptr[r+1]) = sorted(items_in[same range]) for every row r (mask_sort.hip).  Call once with
 // temp == NULL to learn *temp_bytes, then with the scratch.  id_bits = bits needed for the largest id.
 hipError_t sort_mask_rows(const uint32_t* items_in, uint32_t* items_out, uint32_t n_items, uint32_t rows,

@@ -43,6 +43,7 @@ template <int CAP> struct __attribute__((aligned(16))) SharedT
     float    topv[TU][CAP]; // per user: the k best so far, best first
     uint32_t topi[TU][CAP];
     float    thr_v[TU];                  // = entry k-1, the one a candidate has to beat
+    float    thr_sh[TU];                 // the best k-th score ANY item split of these users has reached (global exchange)
     uint32_t thr_i[TU];
     uint32_t mbits[TU][4];
     float    qv[4][QW];
@@ -153,6 +154,7 @@ struct FusedArgs
     uint32_t        tiles_per_split;
     const uint64_t* indptr;   // [rows + 1], relative to `items`; NULL = no masking; rows sorted ascending
     const uint32_t* items;
+    float*          thr_shared; // [rows]: max over the item splits of a user's k-th best score so far (-inf at launch)
     float*          part_v;   // [splits, rows, k]
     uint32_t*       part_i;
 };
@@ -219,6 +221,8 @@ template <int CAP> __global__ __launch_bounds__(256, 2) void topk_fused_kernel(F
     if (tid < TU)
     {
         s.thr_v[tid] = -INFINITY;
+        // a split that starts late inherits what the other splits of its users have already found
+        s.thr_sh[tid] = (p.thr_shared && u0 + tid < p.rows) ? __builtin_nontemporal_load(p.thr_shared + u0 + tid) : -INFINITY;
         s.thr_i[tid] = NONE;
     }
     if (tid < 4) s.qn[tid] = 0;
@@ -313,7 +317,9 @@ template <int CAP> __global__ __launch_bounds__(256, 2) void topk_fused_kernel(F
 #pragma unroll
         for (int q = 0; q < 4; ++q)
         {
-            const f4 t4 = *(const f4*)&s.thr_v[wu * 32 + 8 * q + 4 * h];
+            const f4 tl = *(const f4*)&s.thr_v[wu * 32 + 8 * q + 4 * h];
+            const f4 ts = *(const f4*)&s.thr_sh[wu * 32 + 8 * q + 4 * h];
+            const f4 t4 = f4{fmaxf(tl[0], ts[0]), fmaxf(tl[1], ts[1]), fmaxf(tl[2], ts[2]), fmaxf(tl[3], ts[3])};
 #pragma unroll
             for (int j = 0; j < 4; ++j)
             {
@@ -341,7 +347,7 @@ template <int CAP> __global__ __launch_bounds__(256, 2) void topk_fused_kernel(F
                 for (int r2 = 0; r2 < 16; ++r2)
                     if (r2 == r) v = c ? acc1[r2] : acc0[r2];
                 if ((s.mbits[u][wi * 2 + c] >> n) & 1u) v = -INFINITY;
-                if (!(v < s.thr_v[u])) push(s, u, c ? it1 : it0, v);
+                if (!(v < s.thr_v[u]) && !(v < s.thr_sh[u])) push(s, u, c ? it1 : it0, v);
             }
         }
         __syncthreads();
@@ -367,13 +373,27 @@ template <int CAP> __global__ __launch_bounds__(256, 2) void topk_fused_kernel(F
                 for (int r2 = 0; r2 < 16; ++r2)
                     if (r2 == r) v = c ? acc1[r2] : acc0[r2];
                 if ((s.mbits[u][wi * 2 + c] >> n) & 1u) v = -INFINITY;
-                if (u0 + u < p.rows && item < p.num_items && !(v < s.thr_v[u])) push(s, u, item, v);
+                if (u0 + u < p.rows && item < p.num_items && !(v < s.thr_v[u]) && !(v < s.thr_sh[u])) push(s, u, item, v);
                 __syncthreads();
                 drain(s, k, wave, lane);
             }
         }
         __syncthreads();
         if (tid < 4) s.qn[tid] = 0;
+        // Threshold exchange between the item splits of these users.  The k-th best score of ONE split is a valid bound for
+        // all of them (that split alone already holds k better items), so the splits prune like a single pass: ~k ln(n/k)
+        // candidates per user in total instead of per split, and a split that starts late skips its warm-up flood.
+        if (p.thr_shared && tid < TU && u0 + tid < p.rows)
+        {
+            const float mine = s.thr_v[tid];
+            float* g = p.thr_shared + u0 + tid;
+            if (mine > s.thr_sh[tid])
+            {
+                if (mine >= 0.0f) atomicMax(reinterpret_cast<int*>(g), __float_as_int(mine));
+                else atomicMin(reinterpret_cast<unsigned int*>(g), __float_as_uint(mine));
+            }
+            s.thr_sh[tid] = fmaxf(mine, __builtin_nontemporal_load(g));
+        }
     }
     __syncthreads();
     for (int t = tid; t < TU * (int)k; t += 256)
@@ -433,7 +453,7 @@ uint32_t topk_fused_splits(uint32_t rows, uint32_t num_items, uint32_t slots)
 
 hipError_t launch_topk_fused(const float* user_rows, const float* item_w, uint32_t rows, uint32_t num_items,
                              uint32_t emb_dim, uint32_t k, const uint64_t* indptr, const uint32_t* items, uint32_t splits,
-                             float* part_v, uint32_t* part_i, uint32_t* topk, hipStream_t s)
+                             float* part_v, uint32_t* part_i, uint32_t* topk, float* thr_shared, hipStream_t s)
 {
     if (rows == 0 || num_items == 0) return hipSuccess;
     if (k == 0 || k > (uint32_t)TOPK_FUSED_MAX_K || splits == 0 || splits > (uint32_t)TOPK_FUSED_MAX_SPLITS || (emb_dim & 3u))
@@ -444,6 +464,12 @@ hipError_t launch_topk_fused(const float* user_rows, const float* item_w, uint32
     p.tiles_per_split = (ntiles + splits - 1) / splits;
     if ((uint64_t)p.tiles_per_split * (splits - 1) >= ntiles && splits > 1) return hipErrorInvalidValue; // empty split
     p.indptr = indptr; p.items = items; p.part_v = part_v; p.part_i = part_i;
+    p.thr_shared = splits > 1 ? thr_shared : nullptr;
+    if (p.thr_shared)
+    {
+        hipError_t e0 = hipMemsetD32Async((hipDeviceptr_t)thr_shared, (int)0xFF800000u, rows, s);   // -inf
+        if (e0 != hipSuccess) return e0;
+    }
     if (k <= 32) hipLaunchKernelGGL(topk_fused_kernel<32>, dim3((rows + TU - 1) / TU, splits), dim3(256), 0, s, p);
     else hipLaunchKernelGGL(topk_fused_kernel<64>, dim3((rows + TU - 1) / TU, splits), dim3(256), 0, s, p);
     hipError_t err = hipGetLastError();
