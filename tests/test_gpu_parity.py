@@ -445,9 +445,11 @@ def test_recall_ndcg_parity_amazonbooks_shape():
     ro = {m: float(np.mean([r[m] for r in ro_runs])) for m in ms}
     print("gpu", lg, rg, "oracle runs", lo_runs, ro_runs)
     # epoch losses: the first epoch (tiny N(0,0.01^2) rows, every update computed from slightly stale rows) is the most
-    # asynchrony-sensitive one, measured 3.0-4.1 % above the oracle; later epochs agree within ~2 %
+    # asynchrony-sensitive one: 2.028 ... 2.034 over five runs vs the oracle's 1.950 ... 1.953 (+4.0 ... +4.3 %); the second
+    # +3.1 %, later ones within 2 %.  The bands below are those measurements plus 0.7 %, not a target: the north star fixes
+    # Recall / NDCG, asserted next.
     for e_, (a, b) in enumerate(zip(lg, lo)):
-        assert abs(a - b) <= (0.06 if e_ == 0 else 0.035) * b, (lg, lo)
+        assert abs(a - b) <= (0.05 if e_ == 0 else 0.035) * b, (lg, lo)
     assert ro[ms[0]] > 0.05                                       # the model learned something
     assert abs(rg[ms[0]] - ro[ms[0]]) <= 1e-3, (rg, ro_runs)
     assert abs(rg[ms[1]] - ro[ms[1]]) <= 1e-3, (rg, ro_runs)
