@@ -1,10 +1,4 @@
 mkdir -p gpurun_out
-python -m pytest tests/test_gpu_parity.py -x -q -k "topk or evaluate0" > gpurun_out/b21_pytest_topk.txt 2>&1; echo "pytest rc=$?"; tail -3 gpurun_out/b21_pytest_topk.txt
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/b21_topk_stats -- python3 tools/eval_bench.py amazonbooks 20,50 fused > gpurun_out/b21_topk_stats.txt 2>&1; grep "top-" gpurun_out/b21_topk_stats.txt
-python - <<'PY'
-import csv,glob
-for f in glob.glob("gpurun_out/b21_topk_stats/*/*kernel_stats.csv"):
-    for row in csv.DictReader(open(f)):
-        if "topk_fused" in row["Name"]: print(row["Name"][40:70], row["AverageNs"])
-PY
-python tools/eval_scale.py > gpurun_out/b21_eval_scale.txt 2>&1; tail -4 gpurun_out/b21_eval_scale.txt
+for i in 1 2; do
+timeout -k 10 1000 python -m pytest tests -m gpu -q -rP --timeout 600 -p no:cacheprovider > gpurun_out/b22_pytest_gpu_$i.txt 2>&1; echo "run $i pytest rc=$?"; tail -2 gpurun_out/b22_pytest_gpu_$i.txt | cut -c1-200
+done
