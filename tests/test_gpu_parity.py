@@ -511,10 +511,10 @@ def test_recall_ndcg_parity_yelp18_config():
     launch plan (220 eight-wave workgroups = 220 interactions in flight, positives by float atomics, negatives by the
     late re-read write-back) must hold the north-star tolerance: mean Recall@20 / NDCG@20 over the seeds
     within +-1e-3 of the oracle's, and the final-epoch training loss within 3 %."""
-    gpu, ora, name = _statistical_parity("yelp18", n_clusters=64, epochs=8, clip=0.1, seeds=(1, 2, 3, 4))
+    gpu, ora, name = _statistical_parity("yelp18", n_clusters=64, epochs=8, clip=0.1, seeds=(1, 2, 3, 4, 5, 6))
     assert "<32,4,16,8>" in name and "upd=0x1c" in name and "streams=220" in name, name
-    # single runs of either side scatter by ~+-6e-4 around their mean (profiles/r02_yelp18_policy_sweep.txt): four seeds per
-    # side resolve the 1e-3 tolerance on the means
+    # single runs of either side scatter by ~+-6e-4 around their mean (profiles/r02_yelp18_policy_sweep.txt): six seeds per
+    # side resolve the 1e-3 tolerance on the means (measured differences of the means over four suite runs: -7e-4 ... +3e-4)
     assert np.ptp(ora[:, 0]) < 3e-3 and np.ptp(ora[:, 1]) < 3e-3
     assert ora[:, 0].mean() > 0.02                                            # the model learned something
     assert abs(gpu[:, 0].mean() - ora[:, 0].mean()) <= 1e-3, (gpu, ora)
