@@ -8,9 +8,10 @@
 //   memory/array.hpp:46-55     row gather / scatter (here: 16-byte-per-lane buffer loads/stores)
 //
 // Mapping to CDNA4
-//   * one 64-lane wavefront = one sequential interaction stream (the analogue of one OpenMP thread walking a
+//   * one workgroup = one sequential interaction stream (the analogue of one OpenMP thread walking a
 //     `schedule(dynamic,512)` chunk): all interactions of a stream are processed in stored order, so a user's
-//     run is updated sequentially and the user row lives in registers while the user does not change;
+//     run is updated sequentially and the user row lives in registers while the user does not change; a workgroup is
+//     ONE 64-lane wavefront up to 17 rows per interaction and NW = 2..16 wavefronts for wider interactions;
 //   * an embedding row is read by LPR = emb_dim/4 (rounded up to 8/16/32/64) consecutive lanes, 16 B per lane
 //     (one `buffer_load_dwordx4` fetches R = 64/LPR whole rows); row-wise dot products are 4 DPP adds inside
 //     the 16-lane DPP row (+ ds_bpermute steps for 128/256-wide rows);
@@ -21,8 +22,11 @@
 //     (W += -lr*G, G += G_new - G_read), shaped as 256 contiguous bytes per wave instruction through a 1 KiB LDS
 //     transpose tile; default policy: positive row atomic, negative rows overwritten (DESIGN.md "Hogwild at GPU
 //     concurrency").  With AUX = sc1 all row traffic is device-coherent across the 8 XCD L2s;
-//   * large num_negs: NW waves per workgroup share one stream (negative slots split across waves, softmax and user
-//     gradient exchanged through LDS); behaviour aggregation (AGG) keeps W0 and the last 32 gradient pairs in LDS;
+//   * large num_negs: NW waves per workgroup share one stream (negative slots split across waves, every wave draws all
+//     ids itself, softmax statistics and user gradient exchanged through LDS: two barriers per interaction); RR = late
+//     re-read of the negative rows (short read-modify-write window); behaviour aggregation (AGG) keeps W0 (while it
+//     fits) and the last 32 gradient pairs in LDS and splits its history gather and d x d product over the waves;
+//     TS = 12 single-wave streams per workgroup sharing the random-tile sampler's tile, whose weight deltas live in LDS;
 //   * negatives come from Philox4x32-10 keyed by (seed, epoch) with the interaction index as counter: no host
 //     round trip, no sampler state in memory, schedule-independent.
 #include "ccl_device.hpp"

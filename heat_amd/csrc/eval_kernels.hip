@@ -1,5 +1,6 @@
-// eval_kernels.hip — evaluation kernels (gfx950).  Round-1 versions: correct and bandwidth-reasonable; the MFMA-tiled
-// fused U*V^T + top-k is the next step.
+// eval_kernels.hip — the materialised evaluation path (gfx950): dense U*V^T panels for evaluate0 (the reference surface
+// returns the full matrix), train-item masking and k rounds of arg-max for k > 64.  The path the product uses for top-k is
+// the fused matrix-core kernel of topk_fused.hip; this one doubles as its cross-check in the tests.
 #include "eval_kernels.hpp"
 
 #include <math.h>
