@@ -32,6 +32,10 @@
 #include "ccl_device.hpp"
 #include "ccl_train.hpp"
 
+#ifndef HEATCF_PART
+#define HEATCF_PART 0
+#endif
+
 #include <cstdio>
 #include <cstdlib>
 
@@ -922,6 +926,7 @@ __global__ __launch_bounds__(64 * NW * TS) void ccl_train_kernel(TrainArgs a)
     }
 }
 
+#if HEATCF_PART == 0
 // Deterministic fixed-order reduction of the per-stream loss partials (fp64), accumulated into *out.
 __global__ __launch_bounds__(256) void loss_reduce_kernel(const double* part, uint32_t n, double* out)
 {
@@ -1012,6 +1017,8 @@ __global__ __launch_bounds__(64) void sample_negs_kernel(TrainArgs a, uint64_t o
     }
 }
 
+#endif // HEATCF_PART == 0
+
 // ---- dispatch -------------------------------------------------------------------------------------------------
 template <int LPR, int NGW, int NW>
 static hipError_t launch_variant(const TrainArgs& a, uint32_t grid, int aux, hipStream_t s)
@@ -1060,12 +1067,34 @@ static hipError_t launch_variant(const TrainArgs& a, uint32_t grid, int aux, hip
 // (lanes per row, register groups per wave, waves per workgroup): capacity = NGW * (64/LPR) * NW negatives.
 // Per-wave register budget ~ 8 VGPRs per group + ~60; more waves per workgroup instead of more groups per wave once a
 // wave would need > ~20 groups.
-#define HEATCF_VARIANTS(X) \
+// The kernel family is compiled as three translation units of this one source (-DHEATCF_PART=0|1|2: rows of <= 16, 32, 64
+// lanes), so that `make -j` builds them side by side; part 0 also carries everything that is not a template.
+#define HEATCF_VARIANTS_P0(X) \
     X(8, 1, 1) X(8, 2, 1) X(8, 4, 1) X(8, 8, 1) X(8, 16, 1) \
-    X(16, 2, 1) X(16, 4, 1) X(16, 8, 1) X(16, 16, 1) X(16, 16, 2) X(16, 2, 2) X(16, 1, 4) \
-    X(32, 4, 1) X(32, 8, 1) X(32, 16, 1) X(32, 32, 1) X(32, 16, 2) X(32, 8, 4) X(32, 16, 4) X(32, 4, 8) X(32, 2, 16) \
+    X(16, 2, 1) X(16, 4, 1) X(16, 8, 1) X(16, 16, 1) X(16, 16, 2) X(16, 2, 2) X(16, 1, 4)
+#define HEATCF_VARIANTS_P1(X) \
+    X(32, 4, 1) X(32, 8, 1) X(32, 16, 1) X(32, 32, 1) X(32, 16, 2) X(32, 8, 4) X(32, 16, 4) X(32, 4, 8) X(32, 2, 16)
+#define HEATCF_VARIANTS_P2(X) \
     X(64, 8, 1) X(64, 16, 1) X(64, 16, 2) X(64, 16, 4) X(64, 25, 4) X(64, 13, 8) X(64, 16, 8)
+#define HEATCF_VARIANTS(X) HEATCF_VARIANTS_P0(X) HEATCF_VARIANTS_P1(X) HEATCF_VARIANTS_P2(X)
+#if HEATCF_PART == 0
+#define HEATCF_MY_VARIANTS(X) HEATCF_VARIANTS_P0(X)
+#define HEATCF_PART_FN(name) name##_part0
+#elif HEATCF_PART == 1
+#define HEATCF_MY_VARIANTS(X) HEATCF_VARIANTS_P1(X)
+#define HEATCF_PART_FN(name) name##_part1
+#else
+#define HEATCF_MY_VARIANTS(X) HEATCF_VARIANTS_P2(X)
+#define HEATCF_PART_FN(name) name##_part2
+#endif
+hipError_t launch_train_part0(const TrainArgs& a, int lpr, int ng, int nw, uint32_t grid, int aux, hipStream_t s);
+hipError_t launch_train_part1(const TrainArgs& a, int lpr, int ng, int nw, uint32_t grid, int aux, hipStream_t s);
+hipError_t launch_train_part2(const TrainArgs& a, int lpr, int ng, int nw, uint32_t grid, int aux, hipStream_t s);
+int occupancy_part0(int lpr, int ng, int nw, int aux, bool agg, uint32_t emb_dim);
+int occupancy_part1(int lpr, int ng, int nw, int aux, bool agg, uint32_t emb_dim);
+int occupancy_part2(int lpr, int ng, int nw, int aux, bool agg, uint32_t emb_dim);
 
+#if HEATCF_PART == 0
 bool pick_variant(uint32_t emb_dim, uint32_t num_negs, bool single_wave, int* lpr_out, int* ng_out, int* nw_out)
 {
     if (emb_dim == 0 || emb_dim % 4 != 0 || emb_dim > 256 || num_negs == 0) return false;
@@ -1126,8 +1155,16 @@ bool pick_variant(uint32_t emb_dim, uint32_t num_negs, bool single_wave, int* lp
 
 hipError_t launch_train(const TrainArgs& a, int lpr, int ng, int nw, uint32_t grid, int aux, hipStream_t s)
 {
+    if (lpr <= 16) return launch_train_part0(a, lpr, ng, nw, grid, aux, s);
+    if (lpr == 32) return launch_train_part1(a, lpr, ng, nw, grid, aux, s);
+    return launch_train_part2(a, lpr, ng, nw, grid, aux, s);
+}
+#endif // HEATCF_PART == 0
+
+hipError_t HEATCF_PART_FN(launch_train)(const TrainArgs& a, int lpr, int ng, int nw, uint32_t grid, int aux, hipStream_t s)
+{
 #define X(L, G, W) if (lpr == L && ng == G && nw == W) return launch_variant<L, G, W>(a, grid, aux, s);
-    HEATCF_VARIANTS(X)
+    HEATCF_MY_VARIANTS(X)
 #undef X
     return hipErrorInvalidValue;
 }
@@ -1152,12 +1189,20 @@ static int occupancy_variant(int aux, bool agg, uint32_t emb_dim)
     return e == hipSuccess ? blocks : 0;
 }
 
-int query_blocks_per_cu(int lpr, int ng, int nw, int aux, bool agg, uint32_t emb_dim)
+int HEATCF_PART_FN(occupancy)(int lpr, int ng, int nw, int aux, bool agg, uint32_t emb_dim)
 {
 #define X(L, G, W) if (lpr == L && ng == G && nw == W) return occupancy_variant<L, G, W>(aux, agg, emb_dim);
-    HEATCF_VARIANTS(X)
+    HEATCF_MY_VARIANTS(X)
 #undef X
     return 0;
+}
+
+#if HEATCF_PART == 0
+int query_blocks_per_cu(int lpr, int ng, int nw, int aux, bool agg, uint32_t emb_dim)
+{
+    if (lpr <= 16) return occupancy_part0(lpr, ng, nw, aux, agg, emb_dim);
+    if (lpr == 32) return occupancy_part1(lpr, ng, nw, aux, agg, emb_dim);
+    return occupancy_part2(lpr, ng, nw, aux, agg, emb_dim);
 }
 
 hipError_t launch_loss_reduce(const double* part, uint32_t n, double* out, hipStream_t s)
@@ -1193,5 +1238,6 @@ hipError_t launch_sample_negs(const TrainArgs& a, uint32_t grid, uint64_t out_ba
     hipLaunchKernelGGL(sample_negs_kernel, dim3(grid), dim3(64), 0, s, a, out_base, out);
     return hipGetLastError();
 }
+#endif // HEATCF_PART == 0
 
 } // namespace heatcf
