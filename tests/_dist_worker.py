@@ -35,7 +35,8 @@ class OracleWindows:
 
 def main():
     out_dir, mode, window = sys.argv[1], sys.argv[2], int(sys.argv[3])
-    overlap = len(sys.argv) > 4 and sys.argv[4] == "overlap"
+    overlap = len(sys.argv) > 4 and sys.argv[4] in ("overlap", "defer")
+    defer = len(sys.argv) > 4 and sys.argv[4] == "defer"      # bench.py's steady state: the closing exchange of an epoch overlaps too
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     data = np.load(os.path.join(out_dir, "problem.npz"))
@@ -49,9 +50,10 @@ def main():
 
     agg = dict(his=data["his"], masks=data["masks"], w0=data["w0"]) if "w0" in data.files else {}
     tr = ShardedTrainer(clicks, data["uw"], data["iw"], num_negs=N, sync_interactions=window, mode=mode,
-                        engine_factory=oracle_factory, overlap=overlap, **agg)
+                        engine_factory=oracle_factory, overlap=overlap, defer_final=defer, **agg)
     for _ in range(int(data["epochs"])):
         tr.train_one_epoch()
+    tr.sync.finalize()
     uw, iw = tr.weights()
     full_u = tr.gather_user_weights()
     extra = {} if tr.aggregator_weights() is None else {"w0": tr.aggregator_weights()}

@@ -205,3 +205,22 @@ def test_overlapped_exchange_applies_the_other_ranks_deltas_one_window_late(tmp_
     ref = iw + first[0] + first[1]
     want = ref + (reps[0] - ref) + (reps[1] - ref)           # the closing (blocking) exchange
     np.testing.assert_allclose(ranks[0]["iw"], want, rtol=0, atol=1e-6)
+
+
+@pytest.mark.timeout(400)
+def test_deferred_closing_exchange_drains_to_identical_replicas(tmp_path):
+    """bench.py's steady state (overlap + defer_final): the closing exchange of an epoch is left in flight across the epoch
+    boundary; finalize() completes it and makes the replicas bit-identical.  Nothing is lost on the way: with shards that
+    touch disjoint item rows the result is single-process training of the whole list."""
+    clicks, negs, uw, iw, U, N = make_problem(tmp_path, disjoint_items=True, epochs=3)
+    ranks = run_world(tmp_path, "sum", window=97, extra=["defer"])
+    assert np.array_equal(ranks[0]["iw"], ranks[1]["iw"])
+    u1, i1 = uw.copy(), iw.copy()
+    ref = orc.Engine(clicks, u1, i1, num_negs=N, l_r=0.01, clip_val=1.0)
+    for _ in range(3):
+        ref.lr_step()
+        ref.train_range(0, clicks.shape[0], negs)
+        ref.zero_grad()
+        ref.epoch = ref.epoch + 1
+    np.testing.assert_allclose(ranks[0]["iw"], i1, rtol=0, atol=2e-5)
+    np.testing.assert_allclose(np.concatenate([ranks[0]["uw"], ranks[1]["uw"]]), u1, rtol=0, atol=2e-5)
