@@ -36,6 +36,7 @@
 #define HEATCF_PART 0
 #endif
 
+#include <type_traits>
 #include <cstdio>
 #include <cstdlib>
 
@@ -110,7 +111,10 @@ __device__ __forceinline__ void dup_rotations(uint32_t id, bool& hit)
 // barrier, and every wave can count the multiplicity of ITS slots against all ids with one compare + ballot per slot
 // instead of a num_negs-iteration scan.  The draws do not depend on table data, so the kernel evaluates them for the
 // NEXT interaction in the shadow of the current gather.
-template <int NIDA>
+// EXT = false compiles the caller-fed path (a global load) away: the draw that runs in the shadow of a gather must not
+// hand the compiler a value that MAY come from memory, or it waits for every outstanding load (vmcnt counts in order)
+// before the multiplicity count and the shadow is gone.
+template <int NIDA, bool EXT = true>
 __device__ __forceinline__ void draw_all_ids(const TrainArgs& a, uint64_t idx, uint32_t pos, uint64_t first, int lane,
                                              uint32_t (&nid)[NIDA])
 {
@@ -119,7 +123,7 @@ __device__ __forceinline__ void draw_all_ids(const TrainArgs& a, uint64_t idx, u
     {
         const uint32_t slot = (uint32_t)(v * 64 + lane);
         uint32_t id;
-        if (a.ext_negs != nullptr)
+        if (EXT && a.ext_negs != nullptr)
         {
             id = slot < a.num_negs ? a.ext_negs[(idx - a.ext_base) * a.num_negs + slot] : 0u;
         }
@@ -597,13 +601,13 @@ __global__ __launch_bounds__(64 * NW * TS) void ccl_train_kernel(TrainArgs a)
             {
                 // multiplicities were counted with the draw; now, while the gather is in flight, draw the NEXT interaction
                 cmax = cmax_w;
-                have_next = (j + 1 < cnt);
+                have_next = (j + 1 < cnt) && a.ext_negs == nullptr;      // caller-fed ids (tests) are fetched at the top instead
                 if (have_next)
                 {
                     const uint32_t pos_n = (uint32_t)__builtin_amdgcn_readlane((int)pair.y, j + 1);
 #pragma unroll
                     for (int v = 0; v < NIDA; ++v) nxt_nid[v] = nid_all[v];
-                    draw_all_ids<NIDA>(a, idx + 1, pos_n, first, lane, nxt_nid);
+                    draw_all_ids<NIDA, false>(a, idx + 1, pos_n, first, lane, nxt_nid);
                     nxt_cmax = slot_multiplicity<NIDA, NGW, R>(nxt_nid, N, wave_base, lane, rr, nxt_mult);
                 }
 #pragma unroll
@@ -748,6 +752,15 @@ __global__ __launch_bounds__(64 * NW * TS) void ccl_train_kernel(TrainArgs a)
                     wpf[RR ? g : 0] = buf_load<AUX>(item_w, noff[g]);
                 }
             }
+            // The sweep exists in three forms (MODE): 0 = plain stores, 1 = negative-row atomics, 2 = the policy bits tested
+            // per row group.  Where the G (and W) rows are fetched a few groups ahead of their use, the (wave-uniform) policy
+            // picks form 0 or 1 OUTSIDE the loop: with the test inside, the compiler's vmcnt bookkeeping merged the atomic and
+            // the plain branch after every row group and made each group wait for the stores of the one before (Yelp18 shape:
+            // 34.2 -> 29.6 ms per epoch).  The wide multi-wave kernels without the late re-read fetch all their G rows before
+            // the first store, lose nothing to that merge, and keep form 2 (the straight-line forms cost them registers).
+            auto sweep = [&](auto mode_tag) __attribute__((always_inline))
+            {
+            constexpr int MODE = decltype(mode_tag)::value;
 #pragma unroll
             for (int g = 0; g < NGW; ++g)
             {
@@ -801,7 +814,7 @@ __global__ __launch_bounds__(64 * NW * TS) void ccl_train_kernel(TrainArgs a)
                     }
                     buf_store<AUX>(item_g, woff, gn);                           // :149
                 }
-                else if (!neg_w_atomic && !neg_g_atomic)
+                else if (MODE == 0 || (MODE == 2 && !neg_w_atomic && !neg_g_atomic))
                 {
                     buf_store<AUX>(item_w, woff, w_base - lr * gn);             // sgd.cpp:23, :148
                     buf_store<AUX>(item_g, woff, gn);                           // :149
@@ -816,6 +829,11 @@ __global__ __launch_bounds__(64 * NW * TS) void ccl_train_kernel(TrainArgs a)
                 }
                 if ((g % GPF) == GPF - 1) __builtin_amdgcn_sched_barrier(0);    // bound how far G fetches are hoisted
             }
+            };
+            if constexpr (RR || TS > 1) sweep(std::integral_constant<int, 0>{});    // bits 0-1 are rejected with bit 4 (engine.cpp)
+            else if constexpr (NW > 1 || NGW > 16) sweep(std::integral_constant<int, 2>{});
+            else if (!neg_w_atomic && !neg_g_atomic) sweep(std::integral_constant<int, 0>{});
+            else sweep(std::integral_constant<int, 1>{});
             gu_acc.x = cross_sum<LPR>(gu_acc.x);
             gu_acc.y = cross_sum<LPR>(gu_acc.y);
             gu_acc.z = cross_sum<LPR>(gu_acc.z);

@@ -207,6 +207,8 @@ int make_plan(const heat_cf_config* cfg, uint64_t data_rows, uint64_t fill, Plan
     else return fail(HEAT_CF_EINVAL, "bad update_mode");
     if (bits != 0u && coh != HEAT_CF_COHERENCE_DEVICE)
         return fail(HEAT_CF_EINVAL, "atomic / re-read update modes need HEAT_CF_COHERENCE_DEVICE");
+    if ((bits & 0x10u) && (bits & 0x3u))
+        return fail(HEAT_CF_EINVAL, "the late re-read (bit 4) applies to plain negative-row stores: bits 0-1 must be clear");
     if ((bits & 0x10u) && cfg->use_aggregator) return fail(HEAT_CF_EUNSUP, "the late re-read write-back is not built for behaviour aggregation");
     // The reference's literal overwrite loses updates in proportion to the number of concurrent workers (Recall@20 0.099 vs
     // 0.209 at AmazonBooks shape with ~3000 streams, profiles/r01_recall_parity_overwrite_modes.txt): without an explicit

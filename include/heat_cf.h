@@ -74,7 +74,8 @@ extern "C" {
 /* values 16..47: raw policy bits (16 + bit0 neg W atomic + bit1 neg G atomic + bit2 pos W atomic + bit3 pos G atomic
  *                + bit4 "late re-read": a negative row's W is read again next to its G row just before its update and the
  *                update is applied to that fresh value — the read-modify-write window of a negative row shrinks from
- *                the whole interaction to one memory round trip; needs HEAT_CF_COHERENCE_DEVICE) */
+ *                the whole interaction to one memory round trip; needs HEAT_CF_COHERENCE_DEVICE and plain negative-row
+ *                stores, i.e. bits 0-1 clear) */
 
 /* Replaces cf::modules::CFConfig (modules/cf_config.hpp:12-35; bound at pybind/init_modules.cpp:13-33).
  * The first 13 fields are the reference's, in its constructor order.  The rest are extensions the

@@ -238,6 +238,10 @@ def test_launch_plan_host_logic():
     assert abi.plan(coherence=abi.COHERENCE_PLAIN, **A)["update_mode"] == "OVERWRITE"
     with pytest.raises(ValueError):
         abi.plan(coherence=abi.COHERENCE_PLAIN, update_mode=abi.UPDATE_ATOMIC_WG, **A)
+    # the late re-read applies to plain negative-row stores: bit 4 together with a negative-row atomic is refused
+    assert abi.plan(update_mode=16 + 0x10, **A)["update_bits"] == 0x10
+    with pytest.raises(ValueError):
+        abi.plan(update_mode=16 + 0x1E, **A)
     # variant table: Yelp18 (d128, N64) -> 32 lanes/row, 4 groups x 8 waves; synthetic-HBM (d256, N100) -> 13 groups x 8 waves (4 % capacity slack)
     y = abi.plan(emb_dim=128, num_negs=64, num_users=31668, num_items=38048, train_size=1237259)
     # 65 rows per interaction: 0.45 in-flight touches per item row with the late re-read write-back (263 streams) and at

@@ -895,7 +895,7 @@ def test_randomized_serial_parity_sweep():
     workgroups, atomics vs stores)."""
     rng = np.random.default_rng(2024)
     modes = [abi.UPDATE_OVERWRITE, abi.UPDATE_ATOMIC_W, abi.UPDATE_ATOMIC_WG, abi.UPDATE_ATOMIC_POS, abi.UPDATE_AUTO,
-             16 + 0x1C, 16 + 0x1E]   # raw bits: late re-read of negative rows (+ positives atomic, + negative G atomic)
+             16 + 0x1C, 16 + 0x10]   # raw bits: late re-read of negative rows (positives atomic / nothing atomic)
     for case in range(40):
         d = int(rng.choice([4, 8, 12, 20, 32, 48, 64, 96, 128, 160, 256]))
         N = int(rng.choice([1, 2, 3, 5, 8, 16, 17, 31, 32, 50, 64, 100]))
