@@ -147,10 +147,36 @@ __device__ __forceinline__ uint32_t slot_multiplicity(const uint32_t (&nid)[NIDA
                                                       int rr, uint32_t (&mult)[NGW])
 {
     uint32_t cmax = 1u;
+    // pass 1, branch-free scalar code: the largest multiplicity among the wave's slots (duplicates are rare: N^2/2I of the
+    // interactions); pass 2 below, the per-slot bookkeeping, only runs when there is one
+    uint32_t most = 0u;
 #pragma unroll
     for (int g = 0; g < NGW; ++g)
     {
         mult[g] = 1u;
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+        {
+            const uint32_t gslot = wave_base + (uint32_t)(g * R + r);          // wave-uniform
+            uint32_t sid = (uint32_t)__builtin_amdgcn_readlane((int)nid[0], (int)(gslot & 63u));
+#pragma unroll
+            for (int v = 1; v < NIDA; ++v)
+            {
+                const uint32_t t = (uint32_t)__builtin_amdgcn_readlane((int)nid[v], (int)(gslot & 63u));
+                sid = (int)(gslot >> 6) == v ? t : sid;
+            }
+            uint32_t eq = 0u;
+#pragma unroll
+            for (int v = 0; v < NIDA; ++v)
+                eq += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(nid[v] == sid && (uint32_t)(v * 64 + lane) < N));
+            eq = gslot < N ? eq : 0u;
+            most = eq > most ? eq : most;
+        }
+    }
+    if (most <= 1u) return cmax;
+#pragma unroll
+    for (int g = 0; g < NGW; ++g)
+    {
 #pragma unroll
         for (int r = 0; r < R; ++r)
         {
@@ -714,16 +740,19 @@ __global__ __launch_bounds__(64 * NW * TS) void ccl_train_kernel(TrainArgs a)
                     sh_stat[wave * 2 + 1] = ssum;
                 }
                 __syncthreads();                                        // B2
-                float big = -INFINITY;
-#pragma unroll
-                for (int w = 0; w < NW; ++w) big = fmaxf(big, sh_stat[w * 2]);
-                float tot = 0.0f;
-#pragma unroll
-                for (int w = 0; w < NW; ++w)
-                {
-                    const float mw = sh_stat[w * 2];
-                    tot += (mw == -INFINITY) ? 0.0f : sh_stat[w * 2 + 1] * expf(mw - big);
-                }
+                // lane l takes the pair of wave l % NW: one expf per lane and a log2(NW)-step DPP tree instead of NW expf's
+                // per wave (every wave runs the same tree on the same pairs, so the replicated results stay identical)
+                const float mw = sh_stat[(lane & (NW - 1)) * 2], sw = sh_stat[(lane & (NW - 1)) * 2 + 1];
+                float big = mw;
+                big = fmaxf(big, dpp_mov<0xB1>(big));                               // xor 1
+                if (NW >= 4) big = fmaxf(big, dpp_mov<0x4E>(big));                  // xor 2
+                if (NW >= 8) big = fmaxf(big, dpp_mov<0x141>(big));                 // other quad of the 8 lanes
+                if (NW >= 16) big = fmaxf(big, dpp_mov<0x140>(big));                // other half of the 16 lanes
+                float tot = (mw == -INFINITY) ? 0.0f : sw * expf(mw - big);
+                tot += dpp_mov<0xB1>(tot);
+                if (NW >= 4) tot += dpp_mov<0x4E>(tot);
+                if (NW >= 8) tot += dpp_mov<0x141>(tot);
+                if (NW >= 16) tot += dpp_mov<0x140>(tot);
                 const float scale = (mx == -INFINITY) ? 0.0f : expf(mx - big);
 #pragma unroll
                 for (int g = 0; g < NGW; ++g) es[g] *= scale;
