@@ -33,6 +33,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
 INFINITY_CACHE_BYTES = 256 << 20
+MEASURED_RMW_CEILING_GBS = {"infinity-cache": 8301.9, "hbm": 6185.2}   # profiles/r01_memory_ceilings.txt (256-B rows)
 
 
 def usable_cpus():
@@ -83,10 +84,16 @@ def roofline(B, B_rd, interactions, kernel_ms, launches, working_set_bytes, traf
     per_launch_s = kernel_ms * 1e-3 / max(launches, 1)
     per_launch = interactions / max(launches, 1)
     achieved = B * per_launch / per_launch_s / 1e9
+    resident = working_set_bytes <= INFINITY_CACHE_BYTES
+    # what a bare random-row read-modify-write loop reaches on this memory system (tools/ceilings.hip, measured in round 1,
+    # profiles/r01_memory_ceilings.txt): context for `frac`, which stays quoted against the nominal HBM peak
+    ceiling = MEASURED_RMW_CEILING_GBS["infinity-cache" if resident else "hbm"]
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "read_frac": B_rd * per_launch / per_launch_s / 1e9 / HBM_PEAK_GBS,
+            "measured_ceiling": ceiling, "frac_of_measured_ceiling": achieved / ceiling,
+            "measured_ceiling_source": "profiles/r01_memory_ceilings.txt: random-row read-modify-write, same residency",
             "traffic": traffic, "traffic_unit": "GB per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)", "traffic_source": traffic_source,
-            "residency": "infinity-cache" if working_set_bytes <= INFINITY_CACHE_BYTES else "hbm",
+            "residency": "infinity-cache" if resident else "hbm",
             "working_set_mb": working_set_bytes / 1e6,
             "algorithmic_gb_per_launch": B * per_launch / 1e9, "bytes_per_interaction": B,
             "read_bytes_per_interaction": B_rd, "kernel_ms_per_launch": per_launch_s * 1e3, "launches": launches}

@@ -272,7 +272,10 @@ int common_init(heat_cf_engine* e, const heat_cf_config* cfg, uint64_t data_rows
     // resident workgroups per CU as the runtime reports them for this variant (register / LDS limited)
     int per_cu = query_blocks_per_cu(e->lpr, e->ng, e->nw, e->aux, cfg->use_aggregator != 0, (uint32_t)cfg->emb_dim);
     if (per_cu < 1) per_cu = 1;
-    prc = make_plan(cfg, data_rows, (uint64_t)e->cu_count * (uint64_t)per_cu, &plan, history_rows, e->cu_count);
+    uint64_t fill = (uint64_t)e->cu_count * (uint64_t)per_cu;
+    // the tile-resident kernel (below) has its own shape: one workgroup of TILE_STREAMS streams per compute unit
+    if (tile_fits_lds(cfg, plan)) fill = (uint64_t)e->cu_count * (uint64_t)TILE_STREAMS;
+    prc = make_plan(cfg, data_rows, fill, &plan, history_rows, e->cu_count);
     if (prc) return prc;
     e->auto_streams = plan.streams;
     e->upd = (int)plan.upd_bits;

@@ -1,0 +1,33 @@
+# Copies the summaries of tools/final_profile.sh (gpurun_out/final/, scratch) into profiles/ under this round's names and
+# derives the per-launch memory-side traffic from the two PMC passes.   usage: bash tools/collect_profiles.sh r02
+set -e
+r=${1:-r02}; o=gpurun_out/final; p=profiles
+newest() { ls -t $1 | head -1; }
+cp $o/bench_n1.json $p/${r}_bench_n1.json
+cp $o/bench_under_rocprof.json $p/${r}_bench_under_rocprof.json
+cp $(newest "$o/prof/*/*_kernel_stats.csv") $p/${r}_bench_kernel_stats.csv
+cp $(newest "$o/pmc_fetch/*/*_counter_collection.csv") $p/${r}_pmc_fetch_counter_collection.csv
+cp $(newest "$o/pmc_write/*/*_counter_collection.csv") $p/${r}_pmc_write_counter_collection.csv
+cp $o/bench_hbm_under_rocprof.json $p/${r}_bench_hbm.json
+cp $(newest "$o/prof_hbm/*/*_kernel_stats.csv") $p/${r}_bench_hbm_kernel_stats.csv
+cp $(newest "$o/pmc_fetch_hbm/*/*_counter_collection.csv") $p/${r}_pmc_fetch_hbm_counter_collection.csv
+cp $(newest "$o/pmc_write_hbm/*/*_counter_collection.csv") $p/${r}_pmc_write_hbm_counter_collection.csv
+cp $o/bench_yelp18.json $p/${r}_bench_yelp18.json
+cp $(newest "$o/prof_yelp18/*/*_kernel_stats.csv") $p/${r}_bench_yelp18_kernel_stats.csv
+cp $o/bench_gowalla.json $p/${r}_bench_gowalla.json
+cp $o/bench_gowalla_pr1.json $p/${r}_bench_gowalla_pr1.json
+cp $o/bench_forcesync.json $p/${r}_bench_forcesync.json
+cp $(newest "$o/prof_topk/*/*_kernel_stats.csv") $p/${r}_topk_kernel_stats.csv
+python - <<PY
+import json, subprocess, sys
+for tag, bench in (("", "$o/bench_n1.json"), ("_hbm", "$o/bench_hbm_under_rocprof.json")):
+    d = json.load(open(bench))
+    rf = d["roofline"] if tag == "" else d.get("roofline_hbm_resident", d["roofline"])
+    kernel = (d["config"]["kernel"] if tag == "" else rf.get("kernel", d["config"]["kernel"]))
+    inter = round(rf["algorithmic_gb_per_launch"] * 1e9 / rf["bytes_per_interaction"])
+    subprocess.check_call([sys.executable, "tools/pmc_traffic.py", "$p/${r}_pmc_fetch%s_counter_collection.csv" % tag,
+                           "$p/${r}_pmc_write%s_counter_collection.csv" % tag, "$p/${r}_pmc_traffic%s.json" % tag, kernel,
+                           str(inter), str(rf["bytes_per_interaction"]), d["config"]["workload"]], stdout=subprocess.DEVNULL)
+    t = json.load(open("$p/${r}_pmc_traffic%s.json" % tag))
+    print(tag or "headline", kernel, "traffic/algorithmic =", round(t["traffic_over_algorithmic"], 4))
+PY
