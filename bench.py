@@ -196,6 +196,35 @@ def tile_sampler_leg(clicks_t, n, uw_h, iw_h, dev, stream, U, I, d, N, steps):
     return out
 
 
+def accl_leg(graph, d, N, steps):
+    """the same graph trained with behaviour aggregation (ACCL) on the GPU — histories of up to 100
+    items per user, W0 d x d; algorithmic bytes add the history rows an interaction reads (W0 lives in LDS)."""
+    from heat_amd import abi
+    from heat_amd.cf import synthetic
+    his, masks = synthetic.make_history(graph, 100, seed=2022)
+    uw, iw = synthetic.init_embeddings(graph.num_users, graph.num_items, d, seed=2022)
+    w0 = (np.random.default_rng(2022).standard_normal((d, d)) * 0.01).astype(np.float32)
+    eng = abi.Engine(graph.clicks, uw, iw, num_negs=N, seed=2022, his=his, masks=masks, w0=w0, use_aggregator=True,
+                     flags=abi.FLAG_LAZY_SYNC)
+    n = graph.clicks.shape[0]
+    eng.train_one_epoch()
+    eng.kernel_time(reset=True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        eng.train_one_epoch()
+    dt = time.perf_counter() - t0
+    kernel_ms, launches = eng.kernel_time()
+    mean_h = float(masks[graph.clicks[:, 0].astype(np.int64)].mean())        # history rows read per interaction
+    B = 16 * d * (N + 2) + 16 + int(round(mean_h * 4 * d))
+    per_launch_s = kernel_ms * 1e-3 / max(launches, 1)
+    out = {"value": n * steps / dt, "unit": "samples/s", "kernel": eng.kernel_name, "kernel_ms_per_launch": per_launch_s * 1e3,
+           "mean_history_rows_per_interaction": mean_h, "bytes_per_interaction": B,
+           "achieved": B * n / per_launch_s / 1e9, "peak": HBM_PEAK_GBS, "frac": B * n / per_launch_s / 1e9 / HBM_PEAK_GBS,
+           "note": "behaviour aggregation (ACCL): stream count held by the Recall/NDCG bound of DESIGN.md section 3, not by the chip"}
+    eng.close()
+    return out
+
+
 def host_mode_leg(graph, d, N, steps, pinned):
     """The same epoch through the reference's own boundary: `cf_c` objects on host numpy buffers, trained in place and
     written back after every epoch (init_modules.cpp:79-81 contract).  pinned=True: the weight arrays live in page-locked
@@ -433,6 +462,8 @@ def main():
                                      "them / plain pageable numpy arrays")
             out["tile_sampler"] = tile_sampler_leg(torch.from_numpy(graph.clicks.view(np.int64)).to(dev), T, uw_h, iw_h, dev, stream,
                                                    U, I, d, N, k)
+            with stdout_to_stderr():
+                out["accl"] = accl_leg(graph, d, N, max(2, k // 2))
             out["roofline_hbm_resident"] = hbm_resident_leg(dev, stream, 4_000_000)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(graph, d, N)

@@ -181,8 +181,11 @@ int make_plan(const heat_cf_config* cfg, uint64_t data_rows, uint64_t fill, Plan
     p->cap_users = (uint32_t)std::min<uint64_t>(0xFFFFFFFFull, std::max<uint64_t>(1, data_rows / min_slice));
     uint64_t streams = std::min<uint64_t>(p->cap_items, p->cap_users);
     if (fill) streams = std::min(streams, fill);
-    // a few workgroups more than a whole number per compute unit would make those units the tail of the launch
-    if (cus && streams > cus && streams < 4ull * cus) streams -= streams % cus;
+    // a few workgroups more than a whole number per compute unit would make those units the tail of the launch — for the
+    // multi-wave workgroups, which run at what the memory system sustains; a single-wave stream between 1x and 4x the
+    // CU count is latency-bound and simply scales with the count (behaviour aggregation at AmazonBooks shape: 256
+    // streams 55.5 ms per epoch, 438 streams 34.9 ms)
+    if (cus && p->nw > 1 && streams > cus && streams < 4ull * cus) streams -= streams % cus;
     if (streams < 1) streams = 1;
     if (cfg->num_streams) streams = cfg->num_streams;
     if (cfg->flags & HEAT_CF_FLAG_SERIAL) streams = 1;
