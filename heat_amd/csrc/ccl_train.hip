@@ -1200,6 +1200,20 @@ bool pick_variant(uint32_t emb_dim, uint32_t num_negs, bool single_wave, int* lp
     return true;
 }
 
+// Behaviour aggregation: the same capacity spread over up to 4 waves (<L, G, 1> -> <L, G/W, W>), where such a variant is
+// compiled.  The aggregator's history gather and d x d product split over the waves, and its streams are latency-bound at
+// the count the Recall bound allows: AmazonBooks shape, 438 streams, <16,4,1> 35.1 ms per epoch, <16,2,2> 34.2, <16,1,4> 25.7.
+void widen_for_aggregator(int lpr, int* ng, int* nw)
+{
+    if (std::getenv("HEAT_CF_VARIANT") || *nw != 1) return;
+    int best_w = 1, best_g = *ng;
+#define X(L, G, W) if (L == lpr && W > best_w && W <= 4 && G * W == *ng) { best_w = W; best_g = G; }
+    HEATCF_VARIANTS(X)
+#undef X
+    *ng = best_g;
+    *nw = best_w;
+}
+
 hipError_t launch_train(const TrainArgs& a, int lpr, int ng, int nw, uint32_t grid, int aux, hipStream_t s)
 {
     if (lpr <= 16) return launch_train_part0(a, lpr, ng, nw, grid, aux, s);

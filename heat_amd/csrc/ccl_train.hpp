@@ -64,6 +64,7 @@ inline bool agg_w0_fits_lds(uint32_t emb_dim, int lpr, int nw) { return agg_lds_
 inline uint64_t epoch_key(uint64_t seed, uint64_t epoch) { return seed + 0x9E3779B97F4A7C15ull * (epoch + 1ull); }
 
 bool       pick_variant(uint32_t emb_dim, uint32_t num_negs, bool single_wave, int* lpr, int* ng, int* nw);
+void       widen_for_aggregator(int lpr, int* ng, int* nw);
 hipError_t launch_train(const TrainArgs& a, int lpr, int ng, int nw, uint32_t grid, int aux, hipStream_t s);
 int        query_blocks_per_cu(int lpr, int ng, int nw, int aux, bool agg, uint32_t emb_dim);
 hipError_t launch_loss_reduce(const double* part, uint32_t n, double* out, hipStream_t s);

@@ -117,10 +117,11 @@ int validate_cfg(const heat_cf_config* cfg, uint64_t data_rows, int* lpr, int* n
     if (cfg->neg_sampler != 0 && cfg->neg_sampler != 1) return fail(HEAT_CF_EINVAL, "neg_sampler must be 0 or 1");
     if (cfg->neg_sampler == 1 && (cfg->tile_size == 0 || cfg->tile_size > 0xFFFFFFFFull || cfg->refresh_interval == 0))
         return fail(HEAT_CF_EINVAL, "random-tile sampler needs tile_size > 0 and refresh_interval > 0");
-    // behaviour aggregation keeps the single-wave variant it was validated with wherever one holds num_negs; the multi-wave
-    // aggregator (history gather and d x d product split over the waves) takes over beyond that
-    if (!(cfg->use_aggregator && pick_variant((uint32_t)cfg->emb_dim, (uint32_t)cfg->num_negs, true, lpr, ng, nw)) &&
-        !pick_variant((uint32_t)cfg->emb_dim, (uint32_t)cfg->num_negs, false, lpr, ng, nw))
+    // behaviour aggregation sizes itself by the single-wave table wherever one holds num_negs (the multi-wave table takes
+    // over beyond that) and then spreads that capacity over up to 4 waves: history gather and d x d product split over them
+    if (cfg->use_aggregator && pick_variant((uint32_t)cfg->emb_dim, (uint32_t)cfg->num_negs, true, lpr, ng, nw))
+        widen_for_aggregator(*lpr, ng, nw);
+    else if (!pick_variant((uint32_t)cfg->emb_dim, (uint32_t)cfg->num_negs, false, lpr, ng, nw))
         return fail(HEAT_CF_EUNSUP, "no compiled kernel variant for this (emb_dim, num_negs)");
     if (data_rows >= (1ull << 40)) return fail(HEAT_CF_EINVAL, "data_rows too large");
     return HEAT_CF_OK;
@@ -183,9 +184,9 @@ int make_plan(const heat_cf_config* cfg, uint64_t data_rows, uint64_t fill, Plan
     if (fill) streams = std::min(streams, fill);
     // a few workgroups more than a whole number per compute unit would make those units the tail of the launch — for the
     // multi-wave workgroups, which run at what the memory system sustains; a single-wave stream between 1x and 4x the
-    // CU count is latency-bound and simply scales with the count (behaviour aggregation at AmazonBooks shape: 256
-    // streams 55.5 ms per epoch, 438 streams 34.9 ms)
-    if (cus && p->nw > 1 && streams > cus && streams < 4ull * cus) streams -= streams % cus;
+    // CU count, and a behaviour-aggregation stream of any shape, is latency-bound and simply scales with the count
+    // (aggregation at AmazonBooks shape: 256 streams 55.5 ms per epoch, 438 streams 34.9 ms)
+    if (cus && p->nw > 1 && !cfg->use_aggregator && streams > cus && streams < 4ull * cus) streams -= streams % cus;
     if (streams < 1) streams = 1;
     if (cfg->num_streams) streams = cfg->num_streams;
     if (cfg->flags & HEAT_CF_FLAG_SERIAL) streams = 1;

@@ -264,9 +264,13 @@ def test_launch_plan_host_logic():
     # masked shapes: emb_dim 20 -> 8 lanes/row (5 used); 5 negatives -> 1 group of 8 rows
     m = abi.plan(emb_dim=20, num_negs=5, num_users=100, num_items=1000, train_size=10)
     assert (m["lanes_per_row"], m["negative_capacity"]) == (8, 8)
-    # the aggregator is built for single-wave variants
-    assert abi.plan(emb_dim=128, num_negs=64, num_users=31668, num_items=38048, train_size=10,
-                    use_aggregator=True)["waves_per_workgroup"] == 1
+    # the aggregator sizes itself by the single-wave table and spreads that capacity over up to 4 waves where compiled:
+    # d128 / 64 negatives <32,32>x1 -> <32,8>x4; AmazonBooks config <16,4>x1 -> <16,1>x4; its streams are not rounded to CUs
+    ag = abi.plan(emb_dim=128, num_negs=64, num_users=31668, num_items=38048, train_size=10, use_aggregator=True)
+    assert (ag["lanes_per_row"], ag["groups_per_wave"], ag["waves_per_workgroup"]) == (32, 8, 4)
+    ab = abi.plan(emb_dim=64, num_negs=16, num_users=52643, num_items=91599, train_size=2380730, use_aggregator=True)
+    assert (ab["lanes_per_row"], ab["groups_per_wave"], ab["waves_per_workgroup"]) == (16, 1, 4)
+    assert ab["streams"] % 256 != 0
     # outside the compiled family
     for bad in (dict(emb_dim=6), dict(emb_dim=260), dict(num_negs=500)):
         cfg = dict(emb_dim=64, num_negs=16, num_users=10, num_items=10, train_size=1)

@@ -98,7 +98,9 @@ def test_reference_hyperparameters_short_horizon():
     assert_tables_close(ig, io, scale=np.abs(io).max(), rtol=5e-4)
 
 
-@pytest.mark.parametrize("d,N,H", [(64, 16, 100), (64, 4, 7), (128, 16, 40), (32, 8, 100),
+@pytest.mark.parametrize("d,N,H", [(64, 16, 100),     # AmazonBooks config: <16,4> x 1 spread over 4 waves (<16,1> x 4)
+                                   (128, 64, 50),     # Yelp18 yaml with aggregation: <32,32> x 1 spread to <32,8> x 4
+                                   (64, 4, 7), (128, 16, 40), (32, 8, 100),
                                    (256, 100, 100),   # synthetic 10 M x 1 M config: <64,13> x 8 waves, W0 (256 KB) read from L2
                                    (128, 100, 60),    # <32,16> x 4 waves, W0 copy in LDS
                                    (64, 100, 200),    # <16,16> x 2 waves, history longer than 128
