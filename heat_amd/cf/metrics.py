@@ -71,12 +71,78 @@ _METRICS = {"Recall": _recall, "NormalizedRecall": _normalized_recall, "Precisio
             "DCG": _dcg, "NDCG": _ndcg, "MRR": _mrr, "HitRate": _hit_rate, "MAP": _map}
 
 
+def _score_per_user(top_k_items, true_items, callers):
+    """The reference's scoring loop, one Python call per (user, metric): metrics.py:31-34.  Kept as the definition the
+    vectorised scorer below is checked against (tests/test_frontend_cpu.py); ~2 s per evaluation at AmazonBooks size."""
+    return np.array([[fn([int(x) for x in top], true, k) for fn, k in callers] for top, true in zip(top_k_items, true_items)])
+
+
+def _score_vectorised(top_k_items, true_items, callers):
+    """Same per-user values, bit for bit, from a [users, k] hit matrix: membership by one sorted-key lookup, every sum over
+    the rank positions accumulated position by position in the loop order of the functions above (adding 0.0 for a miss
+    is exact), so the averages equal the per-user loop's.  Needs distinct ids per top-k row (a top-k list has them; _score
+    checks and falls back to the loop otherwise)."""
+    n = min(len(top_k_items), len(true_items))
+    kmax = max(k for _, k in callers)
+    top = np.asarray(top_k_items)[:n, :kmax].astype(np.int64)
+    n_true = np.fromiter((len(t) for t in true_items[:n]), dtype=np.int64, count=n)
+    flat_true = np.fromiter((int(x) for t in true_items[:n] for x in t), dtype=np.int64, count=int(n_true.sum()))
+    span = int(max(top.max(initial=0), flat_true.max(initial=0))) + 1
+    row_of_true = np.repeat(np.arange(n, dtype=np.int64), n_true)
+    keys = np.unique(row_of_true * span + flat_true)
+    query = np.arange(n, dtype=np.int64)[:, None] * span + top
+    pos = np.searchsorted(keys, query)
+    hits = (keys[np.minimum(pos, max(keys.size - 1, 0))] == query) if keys.size else np.zeros_like(query, dtype=bool)
+    hits &= top >= 0
+    ranks = np.arange(kmax)
+    log_w = 1 / np.log(2 + ranks)                                                # _dcg's weights
+    ideal = np.concatenate([[0.0], np.zeros(kmax)])
+    for i in range(kmax):
+        ideal[i + 1] = ideal[i] + log_w[i]                                       # _dcg(true[:k], true, k) by prefix length
+    out = np.zeros((n, len(callers)))
+    for c, (fn, k) in enumerate(callers):
+        h = hits[:, :k]
+        inter = h.sum(axis=1)
+        if fn is _recall:
+            out[:, c] = inter / (n_true + 1e-12)
+        elif fn is _normalized_recall:
+            out[:, c] = inter / np.minimum(k, n_true + 1e-12)
+        elif fn is _precision:
+            out[:, c] = inter / (k + 1e-12)
+        elif fn is _f1:
+            p, r = inter / (k + 1e-12), inter / (n_true + 1e-12)
+            out[:, c] = 2 * p * r / (p + r + 1e-12)
+        elif fn is _hit_rate:
+            out[:, c] = inter > 0
+        elif fn in (_dcg, _ndcg, _mrr):
+            w = 1 / (ranks[:k] + 1.0) if fn is _mrr else log_w[:k]
+            acc = np.zeros(n)
+            for i in range(k):
+                acc += np.where(h[:, i], w[i], 0.0)
+            out[:, c] = acc / (ideal[np.minimum(n_true, k)] + 1e-12) if fn is _ndcg else acc
+        elif fn is _map:
+            found = np.zeros(n)
+            precision = np.zeros(n)
+            for i in range(k):
+                found += h[:, i]
+                precision += np.where(h[:, i], found / (i + 1.0), 0.0)
+            out[:, c] = precision / (found + 1e-12)
+        else:
+            raise NotImplementedError(fn.__name__)
+    return out
+
+
 def _score(top_k_items, test_items_dic, test_user_ids, metrics, quiet=False):
     callers = [_parse(m) for m in metrics]
     true_items = [test_items_dic[u] for u in test_user_ids]
     # metrics.py:31-32 zips ROW i of the top-k matrix with the i-th test user (not with row `user id`)
-    results = [[fn([int(x) for x in top], true, k) for fn, k in callers] for top, true in zip(top_k_items, true_items)]
-    average_result = np.average(np.array(results), axis=0).tolist()
+    rows = np.asarray(top_k_items)
+    srt = np.sort(rows, axis=1) if rows.ndim == 2 and rows.size else rows
+    if rows.ndim != 2 or rows.shape[0] == 0 or (srt[:, 1:] == srt[:, :-1]).any():    # repeated ids in a row: set semantics
+        results = _score_per_user(top_k_items, true_items, callers)
+    else:
+        results = _score_vectorised(rows, true_items, callers)
+    average_result = np.average(results, axis=0).tolist()
     if not quiet:
         print('[Metrics] ' + ' - '.join('{}: {:.6f}'.format(k, v) for k, v in zip(metrics, average_result)))
     return dict(zip(metrics, average_result))

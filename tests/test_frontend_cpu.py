@@ -47,6 +47,27 @@ def test_evaluate_topk_equals_dense_path(metric_cases):
         assert got[name] == pytest.approx(want, rel=1e-12)
 
 
+def test_vectorised_scorer_equals_the_per_user_loop_bit_for_bit():
+    """metrics._score_vectorised (what evaluate_metrics / evaluate_topk run) against metrics._score_per_user (the
+    reference's loop, metrics.py:31-34) on random lists: every metric, cut-offs above and below the list lengths, users
+    with one item, duplicated test items, hits forced into the head of the list."""
+    rng = np.random.default_rng(5)
+    U, I, k = 400, 900, 50
+    top = np.stack([rng.permutation(I)[:k] for _ in range(U)]).astype(np.uint32)
+    true = [rng.choice(I, int(rng.integers(1, 70)), replace=False).tolist() for _ in range(U)]
+    for u in range(0, U, 3):                                   # some early hits
+        keep = [x for x in top[u] if x not in true[u][:3]]
+        top[u] = np.array(true[u][:3] + keep, dtype=np.uint32)[:k]
+    true[7] = true[7] + true[7][:2]                            # duplicated test items count in len(true), as in the reference
+    names = ["Recall(k=20)", "NDCG(k=20)", "NormalizedRecall(k=10)", "Precision(k=50)", "F1(k=20)", "DCG(k=50)", "MRR(k=20)",
+             "HitRate(k=5)", "MAP(k=50)", "NDCG(k=50)", "Recall(k=1)"]
+    callers = [M._parse(m) for m in names]
+    slow = M._score_per_user(top, true, callers)
+    fast = M._score_vectorised(top, true, callers)
+    assert np.array_equal(slow, fast)
+    assert fast[:, 0].max() > 0 and fast[:, 8].max() > 0
+
+
 def test_unknown_metric_raises():
     with pytest.raises(NotImplementedError):
         M.evaluate_topk(types.SimpleNamespace(user_items_dic={0: [1]}), np.zeros((1, 5), int), ["Bogus(k=3)"])
