@@ -97,7 +97,11 @@ def main(argv=None):
     parser.add_argument('--synthetic', type=str, default=None, help='amazonbooks | gowalla | yelp18: seeded synthetic graph')
     parser.add_argument('--scale', type=float, default=1.0)
     parser.add_argument('--distributed', action='store_true', help='use the sharded multi-GPU trainer even with one rank')
-    parser.add_argument('--gpu-topk', action='store_true', help='evaluate with the fused GPU top-k instead of evaluate0()')
+    parser.add_argument('--dense-eval', action='store_true',
+                        help="evaluate as the reference does (main.py:117-121): evaluate0() returns the dense num_users x "
+                             "num_items score matrix to the host, numpy masks / partitions / sorts it.  Default: the fused GPU "
+                             "top-k (same ids, tests/test_gpu_parity.py::test_evaluate0_and_topk) + the same scoring")
+    parser.add_argument('--gpu-topk', action='store_true', help='accepted for older command lines: the fused top-k is the default')
     args = parser.parse_args(argv)
     config_dic = utils.load_config(args.config)
     dataset_config = config_dic['dataset_config']
@@ -146,7 +150,7 @@ def main(argv=None):
             model.eval()
             with torch.no_grad():
                 eva_metrics = ['Recall(k=20)']                                      # main.py:120
-                if args.gpu_topk:
+                if not args.dense_eval:
                     indptr, items = train_data.train_csr()
                     top = engine.topk(20, indptr, items)
                     results = metrics.evaluate_topk(test_data, top, eva_metrics)

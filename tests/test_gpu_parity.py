@@ -707,8 +707,8 @@ def test_frontend_main_runs_through_cf_c(tmp_path, capsys):
     cfg["model_config"]["eval_interval"] = 2
     path = tmp_path / "cfg.yaml"
     path.write_text(yaml.safe_dump(cfg))
-    r_dense = cf_main.main(["--config", str(path), "--synthetic", "gowalla", "--scale", "0.1"])
-    r_topk = cf_main.main(["--config", str(path), "--synthetic", "gowalla", "--scale", "0.1", "--gpu-topk"])
+    r_dense = cf_main.main(["--config", str(path), "--synthetic", "gowalla", "--scale", "0.1", "--dense-eval"])
+    r_topk = cf_main.main(["--config", str(path), "--synthetic", "gowalla", "--scale", "0.1"])
     out = capsys.readouterr().out
     assert "epoch: 2; loss:" in out and "[Metrics] Recall(k=20)" in out
     assert 0.02 < r_dense["Recall(k=20)"] < 1.0

@@ -10,6 +10,6 @@ open("gpurun_out/tile/tile.yaml", "w").write(yaml.safe_dump(c))
 PY
 for S in uniform tile; do
   if [ $S = uniform ]; then C=$CFG; else C=gpurun_out/tile/tile.yaml; fi
-  timeout -k 10 280 python -m heat_amd.cf.main --config $C --synthetic amazonbooks --gpu-topk > gpurun_out/tile/$S.txt 2>&1 || { echo "$S failed"; tail -5 gpurun_out/tile/$S.txt; exit 1; }
+  timeout -k 10 280 python -m heat_amd.cf.main --config $C --synthetic amazonbooks > gpurun_out/tile/$S.txt 2>&1 || { echo "$S failed"; tail -5 gpurun_out/tile/$S.txt; exit 1; }
   echo "== neg_sampler=$S"; grep -h "^epoch:\|Recall" gpurun_out/tile/$S.txt
 done
