@@ -41,47 +41,77 @@ class Dataset(CPPBase):
 
 
 class ClickDataset(Dataset):
-    def __init__(self, file_path=None, separator=' ', config=None, seed=2022, user_items=None, is_train=None, cache=True):
-        """file_path: LightGCN txt; or user_items: {user_id: [items]} (synthetic graphs)."""
+    def __init__(self, file_path=None, separator=' ', config=None, seed=2022, user_items=None, is_train=None, cache=True,
+                 csr=None):
+        """file_path: LightGCN txt; or user_items: {user_id: [items]}; or csr = (indptr, items) over user ids 0..n-1
+        (synthetic graphs).
+
+        Everything sized by the interactions is built from arrays (one CSR of the users' item lists in the reference's
+        iteration order): the history matrix is one gather, the interaction list one repeat — the reference's per-user
+        Python loop (datasets.py:50-78) takes minutes at 10^8 interactions.  `user_items_dic` stays a dict of lists (the
+        metrics and the reference's callers read it); `user_item_ids` (a list of 2.4 M tuples at AmazonBooks size) is
+        materialised only when somebody asks for it."""
         super().__init__()
         self.file_path = file_path if file_path is not None else "<memory>"
-        self.user_items_dic = {}
         self.max_his = config.max_his
         rnd = random.Random(seed)
-        if user_items is None:
+        # ---- users in the reference's dict order, their items as one CSR -------------------------------------------------
+        if csr is not None:
+            indptr, items_all = np.asarray(csr[0], dtype=np.int64), np.asarray(csr[1], dtype=np.uint64)
+            lens = np.diff(indptr)
+            # a train split lists every user (an empty one gets the reference's warning and still counts in num_users);
+            # other splits list the users that have items, as a file would
+            users = (np.arange(lens.size) if is_train else np.flatnonzero(lens > 0)).astype(np.int64)
+            starts, lens = indptr[users], lens[users]
+        elif user_items is None:
             # native one-pass parser (heat_cf_parse_lightgcn) instead of the reference's per-line Python loop
             clicks, line_user, line_start = _parse_cached(file_path, separator, cache)
-            items_all = clicks[:, 1]
-            for k, u in enumerate(line_user.tolist()):
-                self.user_items_dic[u] = items_all[line_start[k]:line_start[k + 1]].tolist()   # a repeated user id: last line wins (datasets.py:56)
+            items_all = np.ascontiguousarray(clicks[:, 1]).astype(np.uint64, copy=False)
+            line_user = np.asarray(line_user, dtype=np.int64)
+            line_start = np.asarray(line_start, dtype=np.int64)
+            # a repeated user id: the dict keeps the position of its FIRST line and the items of its LAST (datasets.py:56)
+            uniq, first = np.unique(line_user, return_index=True)
+            last = len(line_user) - 1 - np.unique(line_user[::-1], return_index=True)[1]
+            order = np.argsort(first, kind="stable")
+            users, src = uniq[order], last[order]
+            starts, lens = line_start[src], line_start[src + 1] - line_start[src]
         else:
-            self.user_items_dic = {int(u): [int(i) for i in items] for u, items in user_items.items()}
+            users = np.fromiter((int(u) for u in user_items), dtype=np.int64, count=len(user_items))
+            lens = np.fromiter((len(v) for v in user_items.values()), dtype=np.int64, count=len(user_items))
+            items_all = np.fromiter((int(i) for v in user_items.values() for i in v), dtype=np.uint64, count=int(lens.sum()))
+            starts = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int64)
+        tolist = items_all.tolist()
+        self.user_items_dic = {int(u): tolist[a:a + n] for u, a, n in zip(users.tolist(), starts.tolist(), lens.tolist())}
         # datasets.py:44-45: one history row per line, indexed by user id (sized by the largest id so that a file
         # that skips users, e.g. a test split, does not index out of range as the reference would)
-        num_lines = max(len(self.user_items_dic), (max(self.user_items_dic) + 1) if self.user_items_dic else 0)
+        num_lines = max(len(users), int(users.max()) + 1 if users.size else 0)
         self.his_items = np.zeros((num_lines, self.max_his), dtype=np.uint64)
         self.masks = np.zeros((num_lines, 1), dtype=np.uint64)
-        item_ids = set()
-        pairs = []
-        for user_id, items in self.user_items_dic.items():
-            if len(items) >= self.max_his:                       # datasets.py:58-61
-                self.his_items[user_id] = rnd.sample(items, self.max_his)
-                self.masks[user_id] = self.max_his
-            elif len(items) > 0:                                 # :62-66 pad with the last item
-                self.his_items[user_id] = items + [items[-1]] * (self.max_his - len(items))
-                self.masks[user_id] = len(items)
-            else:                                                # :67-72
-                print(f"Warning {user_id} has 0 items !!! ")
-            item_ids.update(items)
-            pairs.extend((user_id, it) for it in items)          # :74-78 interactions in file order
-        self.user_item_ids = pairs
+        have = lens > 0
+        for u in users[~have].tolist():                          # datasets.py:67-72
+            print(f"Warning {u} has 0 items !!! ")
+        # :62-66 fewer than max_his items: the list padded with its last item = gather at min(column, len - 1)
+        short = have & (lens < self.max_his)
+        col = np.minimum(np.arange(self.max_his, dtype=np.int64)[None, :], lens[short, None] - 1)
+        self.his_items[users[short]] = items_all[starts[short, None] + col]
+        self.masks[users[short], 0] = lens[short].astype(np.uint64)
+        # :58-61 max_his or more: a seeded random.sample per user, in dict order (as the loop drew them)
+        for u, a, n in zip(users[lens >= self.max_his].tolist(), starts[lens >= self.max_his].tolist(),
+                           lens[lens >= self.max_his].tolist()):
+            self.his_items[u] = rnd.sample(tolist[a:a + n], self.max_his)
+            self.masks[u] = self.max_his
+        # :74-78 interactions in dict order
+        take = np.repeat(starts - np.concatenate([[0], np.cumsum(lens)[:-1]]), lens) + np.arange(int(lens.sum()), dtype=np.int64)
+        self._clicks = np.stack([np.repeat(users.astype(np.uint64), lens), items_all[take]], axis=1) if users.size else \
+            np.zeros((0, 2), dtype=np.uint64)
+        self._pairs = None
         # datasets.py:96-97 count distinct ids and assume they are 0..n-1; sparse id spaces (an item that never occurs in
         # train) would then index past the tables, so the table sizes cover the largest id as well
-        self.num_users = max(len(self.user_items_dic), (max(self.user_items_dic) + 1) if self.user_items_dic else 0)
-        self.num_items = max(len(item_ids), (max(item_ids) + 1) if item_ids else 0)
-        self._min_max = (min(self.user_items_dic) if self.user_items_dic else 0,
-                         max(self.user_items_dic) if self.user_items_dic else 0,
-                         min(item_ids) if item_ids else 0, max(item_ids) if item_ids else 0)
+        item_ids = np.unique(self._clicks[:, 1])
+        self.num_users = num_lines
+        self.num_items = max(int(item_ids.size), int(item_ids[-1]) + 1 if item_ids.size else 0)
+        self._min_max = (int(users.min()) if users.size else 0, int(users.max()) if users.size else 0,
+                         int(item_ids[0]) if item_ids.size else 0, int(item_ids[-1]) if item_ids.size else 0)
         self.gen_dataset_info()
         train = ('train' in self.file_path) if is_train is None else is_train   # datasets.py:82
         if train:
@@ -89,10 +119,17 @@ class ClickDataset(Dataset):
             self.c_class = cf_c.modules.datasets.ClickDataset
             config.num_users = self.num_users
             config.num_items = self.num_items
-            config.train_size = len(self.user_item_ids)
-            self.click_dataset = np.array(self.user_item_ids, dtype=np.uint64).reshape(-1, 2)
+            config.train_size = self._clicks.shape[0]
+            self.click_dataset = np.ascontiguousarray(self._clicks)
             self.init_c_instance(click_dataset=self.click_dataset, historical_items=self.his_items, masks=self.masks)
             self.c_instance.max_his = self.max_his
+
+    @property
+    def user_item_ids(self):
+        """[(user, item), ...] in file order (datasets.py:74-78), built on first use."""
+        if self._pairs is None:
+            self._pairs = list(map(tuple, self._clicks.tolist()))
+        return self._pairs
 
     def gen_dataset_info(self):
         lo_u, hi_u, lo_i, hi_i = self._min_max
@@ -103,7 +140,7 @@ class ClickDataset(Dataset):
             print('Warning item_id is not continuous! ')
         print(f'number of users: {self.num_users}; min_user_id: {lo_u}; max_user_id: {hi_u}')
         print(f'number of items: {self.num_items}; min_item_id: {lo_i}; max_item_id: {hi_i}')
-        print(f'total samples: {len(self.user_item_ids)} ')
+        print(f'total samples: {self._clicks.shape[0]} ')
 
     def get_user_items(self):
         return self.user_items_dic
@@ -111,11 +148,8 @@ class ClickDataset(Dataset):
     def train_csr(self):
         """(indptr u64 [num_users+1], items u32) of this dataset's items per user id — the mask for top-k eval."""
         n = (max(self.user_items_dic) + 1) if self.user_items_dic else 0
-        lens = np.zeros(n, dtype=np.int64)
-        for u, items in self.user_items_dic.items():
-            lens[u] = len(items)
+        users = self._clicks[:, 0].astype(np.int64)
+        lens = np.bincount(users, minlength=n)
         indptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
-        items = np.empty(int(indptr[-1]), dtype=np.uint32)
-        for u, its in self.user_items_dic.items():
-            items[int(indptr[u]):int(indptr[u + 1])] = its
-        return indptr, items
+        order = np.argsort(users, kind="stable")                 # dict order within a user = file order
+        return indptr, self._clicks[order, 1].astype(np.uint32)

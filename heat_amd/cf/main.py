@@ -17,15 +17,8 @@ from .train import Engine
 
 
 def _graph_to_datasets(graph, cf_config, seed):
-    tr, te = {}, {}
-    ti, tp = graph.train_items, graph.train_indptr.astype(np.int64)
-    ep = graph.test_indptr.astype(np.int64)
-    for u in range(graph.num_users):
-        tr[u] = ti[tp[u]:tp[u + 1]].tolist()
-        if ep[u + 1] > ep[u]:
-            te[u] = graph.test_items[ep[u]:ep[u + 1]].tolist()
-    train = ClickDataset(config=cf_config, seed=seed, user_items=tr, is_train=True)
-    test = ClickDataset(config=cf_config, seed=seed, user_items=te, is_train=False)
+    train = ClickDataset(config=cf_config, seed=seed, csr=(graph.train_indptr, graph.train_items), is_train=True)
+    test = ClickDataset(config=cf_config, seed=seed, csr=(graph.test_indptr, graph.test_items), is_train=False)
     return train, test
 
 
