@@ -351,32 +351,35 @@ def test_tile_in_lds_single_stream_equals_tile_in_global_memory():
 def test_tile_in_lds_recall_ndcg_amazonbooks_shape():
     """The resident tile changes who sees a negative update when (the other workgroups: one launch late) and how many
     streams share a tile (12 instead of 1); paper Table 6 reports a Recall drop of at most 1e-3 for random tiling.  At the
-    AmazonBooks config (tile 512, refresh 8192, 5 epochs): Recall@20 / NDCG@20 with the tile in LDS within 1e-3 of the
-    same sampler writing straight to the table, and within 2e-3 of the uniform sampler."""
+    AmazonBooks config (tile 512, refresh 8192, 5 epochs; means over three seeds): Recall@20 / NDCG@20 with the tile in LDS
+    within 1e-3 of the same sampler writing straight to the table, and within 2e-3 of the uniform sampler."""
     import types
     from heat_amd.cf import metrics
     g, d, N = synthetic.make_named("amazonbooks")
-    uw0, iw0 = synthetic.init_embeddings(g.num_users, g.num_items, d, seed=2022)
     ep = g.test_indptr.astype(np.int64)
     test = types.SimpleNamespace(user_items_dic={u: g.test_items[ep[u]:ep[u + 1]].tolist()
                                                  for u in range(g.num_users) if ep[u + 1] > ep[u]})
     ms = ["Recall(k=20)", "NDCG(k=20)"]
-    res = {}
-    for name, kw in (("uniform", dict()),
-                     ("tile-global", dict(neg_sampler=1, tile_size=512, refresh_interval=8192, flags=abi.FLAG_SAMPLING_CALL | abi.FLAG_TILE_GLOBAL | abi.FLAG_LAZY_SYNC)),
-                     ("tile-lds", dict(neg_sampler=1, tile_size=512, refresh_interval=8192, flags=abi.FLAG_SAMPLING_CALL | abi.FLAG_LAZY_SYNC))):
-        kw.setdefault("flags", abi.FLAG_LAZY_SYNC)
-        uw, iw = uw0.copy(), iw0.copy()
-        eng = abi.Engine(g.clicks, uw, iw, num_negs=N, seed=2022, **kw)
-        losses = [eng.train_one_epoch() for _ in range(5)]
-        ms_epoch, n = eng.kernel_time()
-        eng.sync_to_host()
-        kname = eng.kernel_name
-        top = eng.topk(20, mask_indptr=g.train_indptr, mask_items=g.train_items)
-        eng.close()
-        r = metrics.evaluate_topk(test, top, ms, quiet=True, by_user_id=True)
-        res[name] = (r[ms[0]], r[ms[1]])
-        print(f"{name:12s} {kname}: {ms_epoch / n:.3f} ms/epoch, losses {[round(x, 4) for x in losses]}, Recall@20 {r[ms[0]]:.5f} NDCG@20 {r[ms[1]]:.5f}")
+    runs = {}
+    for seed in (2022, 7, 99):     # means over three seeds: one configuration run twice differs by up to 8e-4 in Recall@20
+        uw0, iw0 = synthetic.init_embeddings(g.num_users, g.num_items, d, seed=seed)
+        for name, kw in (("uniform", dict()),
+                         ("tile-global", dict(neg_sampler=1, tile_size=512, refresh_interval=8192, flags=abi.FLAG_SAMPLING_CALL | abi.FLAG_TILE_GLOBAL | abi.FLAG_LAZY_SYNC)),
+                         ("tile-lds", dict(neg_sampler=1, tile_size=512, refresh_interval=8192, flags=abi.FLAG_SAMPLING_CALL | abi.FLAG_LAZY_SYNC))):
+            kw.setdefault("flags", abi.FLAG_LAZY_SYNC)
+            uw, iw = uw0.copy(), iw0.copy()
+            eng = abi.Engine(g.clicks, uw, iw, num_negs=N, seed=seed, **kw)
+            losses = [eng.train_one_epoch() for _ in range(5)]
+            ms_epoch, n = eng.kernel_time()
+            eng.sync_to_host()
+            kname = eng.kernel_name
+            top = eng.topk(20, mask_indptr=g.train_indptr, mask_items=g.train_items)
+            eng.close()
+            r = metrics.evaluate_topk(test, top, ms, quiet=True, by_user_id=True)
+            runs.setdefault(name, []).append((r[ms[0]], r[ms[1]]))
+            print(f"seed {seed} {name:12s} {kname}: {ms_epoch / n:.3f} ms/epoch, losses {[round(x, 4) for x in losses]}, Recall@20 {r[ms[0]]:.5f} NDCG@20 {r[ms[1]]:.5f}")
+    res = {name: tuple(np.mean(v, axis=0)) for name, v in runs.items()}
+    print("means", res)
     assert abs(res["tile-lds"][0] - res["tile-global"][0]) <= 1e-3 and abs(res["tile-lds"][1] - res["tile-global"][1]) <= 1e-3, res
     assert abs(res["tile-lds"][0] - res["uniform"][0]) <= 2e-3 and abs(res["tile-lds"][1] - res["uniform"][1]) <= 2e-3, res
 
@@ -549,13 +552,12 @@ def test_eight_user_shards_match_single_engine_recall_ndcg():
     one real HIP engine per shard taking turns on this GPU, item-table deltas exchanged twice per epoch with the other
     shards' deltas arriving one window late — exactly what `bench.py --gpus 8` runs per rank (ItemSync overlap; the
     all-reduce is a device-side sum over the 8 delta buffers here, tests/shard_sim.py).  Recall@20 / NDCG@20 after the
-    yaml's 5 epochs must stay within +-1e-3 of single-engine training on the whole graph, with each shard engine on its
-    own default launch plan (a stream walks >= 256 interactions: about 1170 streams per shard)."""
+    yaml's 5 epochs (means over three seeds) must stay within +-1e-3 of single-engine training on the whole graph, with each
+    shard engine on its own default launch plan (a stream walks >= 256 interactions: about 1170 streams per shard)."""
     import types
     from heat_amd.cf import metrics
     from tests.shard_sim import train_sharded
     g, d, N = synthetic.make_named("amazonbooks")
-    uw0, iw0 = synthetic.init_embeddings(g.num_users, g.num_items, d, seed=2022)
     ep = g.test_indptr.astype(np.int64)
     test = types.SimpleNamespace(user_items_dic={u: g.test_items[ep[u]:ep[u + 1]].tolist()
                                                  for u in range(g.num_users) if ep[u + 1] > ep[u]})
@@ -568,18 +570,25 @@ def test_eight_user_shards_match_single_engine_recall_ndcg():
         r = metrics.evaluate_topk(test, top, ms, quiet=True, by_user_id=True)
         return r[ms[0]], r[ms[1]]
 
-    uw, iw = uw0.copy(), iw0.copy()
-    eng = abi.Engine(g.clicks, uw, iw, num_negs=N, seed=2022, flags=abi.FLAG_LAZY_SYNC)
-    for _ in range(5):
-        eng.train_one_epoch()
-    eng.sync_to_host()
-    eng.close()
-    single = rank_and_score(uw, iw)
-    su, si, losses, name = train_sharded(g, uw0, iw0, num_negs=N, world=8, epochs=5, windows_per_epoch=2, overlap=True, seed=2022)
-    sharded = rank_and_score(su, si)
-    print("single", single, "8 shards", sharded, name, losses)
-    assert "<16,4,16,1>/upd=0xc" in name and 1024 <= int(name.split("streams=")[1]) <= 1200, name   # shard 0: 300 770 // 256
-    assert abs(sharded[0] - single[0]) <= 1e-3 and abs(sharded[1] - single[1]) <= 1e-3, (single, sharded)
+    # means over three seeds on both sides: two runs of ONE configuration differ by up to 8e-4 in Recall@20 (Hogwild
+    # interleaving), so a single pair cannot resolve the 1e-3 bar
+    singles, shardeds = [], []
+    for seed in (2022, 7, 99):
+        uw0, iw0 = synthetic.init_embeddings(g.num_users, g.num_items, d, seed=seed)
+        uw, iw = uw0.copy(), iw0.copy()
+        eng = abi.Engine(g.clicks, uw, iw, num_negs=N, seed=seed, flags=abi.FLAG_LAZY_SYNC)
+        for _ in range(5):
+            eng.train_one_epoch()
+        eng.sync_to_host()
+        eng.close()
+        singles.append(rank_and_score(uw, iw))
+        su, si, losses, name = train_sharded(g, uw0, iw0, num_negs=N, world=8, epochs=5, windows_per_epoch=2, overlap=True, seed=seed)
+        shardeds.append(rank_and_score(su, si))
+        print("seed", seed, "single", singles[-1], "8 shards", shardeds[-1], name, losses)
+        assert "<16,4,16,1>/upd=0xc" in name and 1024 <= int(name.split("streams=")[1]) <= 1200, name   # shard 0: 300 770 // 256
+    single, sharded = np.mean(singles, axis=0), np.mean(shardeds, axis=0)
+    print("means: single", single, "8 shards", sharded)
+    assert abs(sharded[0] - single[0]) <= 1e-3 and abs(sharded[1] - single[1]) <= 1e-3, (singles, shardeds)
 
 
 def test_overwrite_mode_loses_updates_at_gpu_concurrency():
