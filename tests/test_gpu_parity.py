@@ -418,7 +418,7 @@ def test_recall_ndcg_parity_amazonbooks_shape():
     streams, on-GPU Philox negatives) vs the CPU oracle (8 OpenMP threads, mt19937_64 negatives) within +-1e-3 after the
     yaml's 5 epochs, same synthetic AmazonBooks-shaped graph, same N(0,0.01^2) tables, seed 2022.  The runs draw different
     negatives and interleave differently, and the 8-thread oracle itself is not reproducible (dynamic scheduling moves its
-    NDCG@20 by ~1e-3 between runs), so the GPU is compared with the MEAN of three oracle runs."""
+    NDCG@20 by ~1e-3 between runs), so the MEAN of three GPU runs is compared with the MEAN of three oracle runs."""
     import types
     from heat_amd.cf import metrics
     g, d, N = synthetic.make_named("amazonbooks")
@@ -434,12 +434,16 @@ def test_recall_ndcg_parity_amazonbooks_shape():
         ev.close()
         return metrics.evaluate_topk(test, top, ms, quiet=True, by_user_id=True)
 
-    uw, iw = uw0.copy(), iw0.copy()
-    eng = abi.Engine(g.clicks, uw, iw, num_negs=N, seed=2022, flags=abi.FLAG_LAZY_SYNC)
-    lg = [eng.train_one_epoch() for _ in range(5)]
-    eng.sync_to_host()
-    eng.close()
-    rg = rank_and_score(uw, iw)
+    rg_runs, lg_runs = [], []
+    for _ in range(3):              # the Hogwild GPU run is not reproducible either (Recall@20 moves by up to 8e-4): mean of three
+        uw, iw = uw0.copy(), iw0.copy()
+        eng = abi.Engine(g.clicks, uw, iw, num_negs=N, seed=2022, flags=abi.FLAG_LAZY_SYNC)
+        lg_runs.append([eng.train_one_epoch() for _ in range(5)])
+        eng.sync_to_host()
+        eng.close()
+        rg_runs.append(rank_and_score(uw, iw))
+    lg = np.mean(lg_runs, axis=0)
+    rg = {m: float(np.mean([r[m] for r in rg_runs])) for m in ms}
     ro_runs, lo_runs = [], []
     for _ in range(3):
         uo, io = uw0.copy(), iw0.copy()
@@ -448,7 +452,7 @@ def test_recall_ndcg_parity_amazonbooks_shape():
         ro_runs.append(rank_and_score(uo, io))
     lo = np.mean(lo_runs, axis=0)
     ro = {m: float(np.mean([r[m] for r in ro_runs])) for m in ms}
-    print("gpu", lg, rg, "oracle runs", lo_runs, ro_runs)
+    print("gpu runs", lg_runs, rg_runs, "oracle runs", lo_runs, ro_runs)
     # epoch losses: the first epoch (tiny N(0,0.01^2) rows, every update computed from slightly stale rows) is the most
     # asynchrony-sensitive one: 2.028 ... 2.034 over five runs vs the oracle's 1.950 ... 1.953 (+4.0 ... +4.3 %); the second
     # +3.1 %, later ones within 2 %.  The bands below are those measurements plus 0.7 %, not a target: the north star fixes
@@ -456,8 +460,8 @@ def test_recall_ndcg_parity_amazonbooks_shape():
     for e_, (a, b) in enumerate(zip(lg, lo)):
         assert abs(a - b) <= (0.05 if e_ == 0 else 0.035) * b, (lg, lo)
     assert ro[ms[0]] > 0.05                                       # the model learned something
-    assert abs(rg[ms[0]] - ro[ms[0]]) <= 1e-3, (rg, ro_runs)
-    assert abs(rg[ms[1]] - ro[ms[1]]) <= 1e-3, (rg, ro_runs)
+    assert abs(rg[ms[0]] - ro[ms[0]]) <= 1e-3, (rg_runs, ro_runs)
+    assert abs(rg[ms[1]] - ro[ms[1]]) <= 1e-3, (rg_runs, ro_runs)
 
 
 def _statistical_parity(shape, *, n_clusters, epochs, clip, seeds, lr=0.01):
