@@ -264,6 +264,8 @@ def main():
     ap.add_argument("--num-streams", type=int, default=0)
     ap.add_argument("--windows", type=int, default=0, help="N>1: item-table exchanges per epoch (0 = default, see DESIGN.md section 5)")
     ap.add_argument("--no-overlap", action="store_true", help="N>1: complete every exchange before the next window")
+    ap.add_argument("--collective", default=os.environ.get("HEAT_BENCH_COLLECTIVE", "all_reduce"), choices=("all_reduce", "direct"),
+                    help="N>1: how the item-table deltas are summed over the ranks (heat_amd.cf.distributed.ItemSync)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the HBM-resident, host-mode, literal-window and weak-scaling legs")
     ap.add_argument("--interactions", type=int, default=0,
@@ -388,7 +390,8 @@ def main():
             # default exchange schedule: 2 windows per epoch, every all-reduce overlapped with the next window (also across
             # the epoch boundary); the pipeline is drained inside the timed region
             trainer = ItemSync(eng, item_w, world, windows_per_epoch=args.windows or 2, mode="sum",
-                               force_collective=force_sync, overlap=not args.no_overlap, defer_final=not args.no_overlap)
+                               force_collective=force_sync, overlap=not args.no_overlap, defer_final=not args.no_overlap,
+                               collective=args.collective)
 
     def step():
         if trainer is None:
@@ -416,6 +419,15 @@ def main():
         el = timed(lit.train_one_epoch, k, 1, lit.finalize)
         extra["item_sync_every_8192"] = {"value": T * k / el, "unit": "samples/s", "ms_per_step": el / k * 1e3, "steps": k,
                                          "item_sync": lit.describe(), "exchanges_per_epoch_per_gpu": -(-(T // world) // 8192)}
+        # (a') the headline schedule with the direct exchange (slices scattered to their owners, summed there, gathered
+        # back) instead of RCCL's all-reduce: which one the xGMI links prefer is measured here, not guessed
+        alt_name = "all_reduce" if args.collective == "direct" else "direct"
+        alt = ItemSync(eng, item_w, world, windows_per_epoch=args.windows or 2, mode="sum", overlap=not args.no_overlap,
+                       defer_final=not args.no_overlap, collective=alt_name)
+        k = max(1, min(10, args.steps))
+        el = timed(alt.train_one_epoch, k, 2, alt.finalize)
+        extra["item_sync_" + alt_name] = {"value": T * k / el, "unit": "samples/s", "ms_per_step": el / k * 1e3, "steps": k,
+                                          "item_sync": alt.describe()}
         # (b) weak scaling: every rank its own AmazonBooks-shaped graph (different users, same item space)
         g2 = synthetic.make_graph(U, I, T, seed=2022 + 1000 * (rank + 1), with_test=False)
         eng2, item2 = build(g2.clicks, U, uw_h, (rank + 1) * T, None)

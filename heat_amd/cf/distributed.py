@@ -71,11 +71,19 @@ class ItemSync:
     ranks' deltas then arrive one window late (`W += scale * sum - mine`).  The LAST exchange of an epoch is completed
     before the epoch ends, so the replicas are bit-identical at every epoch boundary — unless defer_final=True, which
     lets it overlap the first window of the next epoch (steady-state throughput runs; call finalize() before reading
-    the table)."""
+    the table).
+
+    collective="all_reduce": one RCCL all-reduce of the delta table (rings / trees over the xGMI links, RCCL's choice).
+    collective="direct"    : the exchange SURVEY section 5 calls the direct 7-peer one, built from RCCL point-to-point
+    collectives: the delta table is cut into world_size slices, slice j of every rank goes straight to rank j
+    (all_to_all: every one of the 7 links of a GPU carries 1/8 of the table once), rank j adds the world_size
+    contributions, and the summed slices are gathered back (all_gather: 1/8 of the table per link again) — 2 x 7/8 of the
+    table over each GPU's links in two steps, against the 2 x 7/8 a ring moves in 14.  Same arithmetic (a sum over
+    ranks in rank order), same apply pass; which one is faster is for the 8-GPU run to say (bench.py times both)."""
 
     def __init__(self, engine, item_w, world_size, refresh_interval=8192, sync_interactions=0, mode="sum", streams=0,
                  force_collective=False, mean_tensors=(), negatives=None, overlap=False, defer_final=False, dist=None,
-                 windows_per_epoch=0):
+                 windows_per_epoch=0, collective="all_reduce"):
         if dist is None:
             import torch.distributed as dist
         self.dist = dist
@@ -98,8 +106,21 @@ class ItemSync:
         self.overlap = bool(overlap) and self.active
         self.defer_final = bool(defer_final) and self.overlap
         self.native = hasattr(engine, "sync_delta") and getattr(item_w, "is_cuda", False)
+        if collective not in ("all_reduce", "direct"):
+            raise ValueError("collective must be 'all_reduce' or 'direct'")
+        self.collective = collective
         self.ref = item_w.clone() if self.active else None
         self.sum = item_w.clone() if self.active else None
+        if self.active and collective == "direct":
+            import torch
+            n, p = item_w.numel(), max(1, world_size)
+            self._chunk = -(-n // p)
+            # the delta lives at the head of a buffer padded to world_size equal slices (the padding stays zero)
+            self._flat = torch.zeros(p * self._chunk, dtype=item_w.dtype, device=item_w.device)
+            self.sum = self._flat[:n].view_as(item_w)
+            self._recv = torch.empty_like(self._flat)
+            self._part = torch.empty(self._chunk, dtype=item_w.dtype, device=item_w.device)
+            self._helper = torch.cuda.Stream(device=item_w.device) if item_w.is_cuda else None
         self.mine = item_w.clone() if self.overlap else None
         self.pending = None                      # (work handle) of an all-reduce in flight
         self._n_max = None
@@ -107,7 +128,9 @@ class ItemSync:
         self.track_loss = False   # True: train_range synchronises per window and the local loss sum is returned
 
     def describe(self):
-        return {"collective": "all_reduce(item table delta)" + (" + all_reduce(W0)" if self.mean_tensors else ""), "mode": self.mode,
+        name = "all_reduce(item table delta)" if self.collective == "all_reduce" else \
+            "all_to_all(delta slices) + local sum + all_gather(summed slices)"
+        return {"collective": name + (" + all_reduce(W0)" if self.mean_tensors else ""), "mode": self.mode,
                 "overlap": self.overlap, "fused_delta_apply_kernels": bool(self.native),
                 "window_interactions_per_gpu": getattr(self, "last_window", min(self.window, self.engine.data_rows)),
                 "exchanges": self.exchanges}
@@ -150,11 +173,36 @@ class ItemSync:
             t.div_(self.world)
         with_mine = not blocking
         self._delta(with_mine)
-        work = self.dist.all_reduce(self.sum, op=self.dist.ReduceOp.SUM, async_op=not blocking)
+        work = self._exchange(blocking)
         self.pending = (work if not blocking else None, with_mine)
         self.exchanges += 1
         if blocking:
             self._complete()
+
+    def _exchange(self, blocking):
+        """Start the sum of `self.sum` over the ranks (in place); returns the handle to wait on (None when done)."""
+        dist = self.dist
+        if self.collective == "all_reduce":
+            return dist.all_reduce(self.sum, op=dist.ReduceOp.SUM, async_op=not blocking)
+        import torch
+        p = max(1, self.world)
+        if self._helper is None:                             # host tensors (gloo tests): plain sequence
+            dist.all_to_all_single(self._recv, self._flat)
+            torch.sum(self._recv.view(p, self._chunk), dim=0, out=self._part)
+            dist.all_gather_into_tensor(self._flat, self._part)
+            return None
+        # the scatter is ordered after the delta kernel on the current stream; the local sum and the gather run on a
+        # helper stream, so that the training stream is not made to wait for either before the next exchange
+        first = dist.all_to_all_single(self._recv, self._flat, async_op=True)
+        self._helper.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self._helper):
+            first.wait()
+            torch.sum(self._recv.view(p, self._chunk), dim=0, out=self._part)
+            work = dist.all_gather_into_tensor(self._flat, self._part, async_op=True)
+        if blocking:
+            work.wait()
+            return None
+        return work
 
     def sync(self, last=True):
         if not self.active:
@@ -225,7 +273,7 @@ class ShardedTrainer:
     def __init__(self, clicks, user_w, item_w, *, num_negs, rank=None, world_size=None, device=None, seed=2022,
                  refresh_interval=8192, sync_interactions=0, mode="sum", engine_factory=None, balance="users",
                  his=None, masks=None, w0=None, negatives=None, overlap=False, defer_final=False, windows_per_epoch=0,
-                 **cfg_kwargs):
+                 collective="all_reduce", **cfg_kwargs):
         import torch
         import torch.distributed as dist
         self.torch = torch
@@ -286,7 +334,7 @@ class ShardedTrainer:
                              mean_tensors=(self.t_w0,) if self.aggregate else (), overlap=overlap, defer_final=defer_final,
                              windows_per_epoch=windows_per_epoch,
                              negatives=None if negatives is None else
-                             np.ascontiguousarray(negatives[base:base + self.shard.shape[0]], dtype=np.uint64))
+                             np.ascontiguousarray(negatives[base:base + self.shard.shape[0]], dtype=np.uint64), collective=collective)
 
     def train_one_epoch(self, want_loss=False):
         """One epoch on this rank's shard.  want_loss=True returns the GLOBAL mean loss (loss sums and interaction counts

@@ -37,6 +37,7 @@ def main():
     out_dir, mode, window = sys.argv[1], sys.argv[2], int(sys.argv[3])
     overlap = len(sys.argv) > 4 and sys.argv[4] in ("overlap", "defer")
     defer = len(sys.argv) > 4 and sys.argv[4] == "defer"      # bench.py's steady state: the closing exchange of an epoch overlaps too
+    collective = sys.argv[5] if len(sys.argv) > 5 else "all_reduce"
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     data = np.load(os.path.join(out_dir, "problem.npz"))
@@ -50,7 +51,7 @@ def main():
 
     agg = dict(his=data["his"], masks=data["masks"], w0=data["w0"]) if "w0" in data.files else {}
     tr = ShardedTrainer(clicks, data["uw"], data["iw"], num_negs=N, sync_interactions=window, mode=mode,
-                        engine_factory=oracle_factory, overlap=overlap, defer_final=defer, **agg)
+                        engine_factory=oracle_factory, overlap=overlap, defer_final=defer, collective=collective, **agg)
     for _ in range(int(data["epochs"])):
         tr.train_one_epoch()
     tr.sync.finalize()
@@ -58,7 +59,7 @@ def main():
     full_u = tr.gather_user_weights()
     extra = {} if tr.aggregator_weights() is None else {"w0": tr.aggregator_weights()}
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), uw=uw, iw=iw, lo=tr.lo, hi=tr.hi, rows=tr.shard.shape[0], full_u=full_u,
-             **extra)
+             collective=np.array(tr.sync.describe()["collective"]), exchanges=tr.sync.exchanges, **extra)
     dist.barrier()
     dist.destroy_process_group()
 

@@ -102,6 +102,24 @@ def test_sum_sync_equals_single_process_when_replicas_touch_disjoint_rows(tmp_pa
 
 
 @pytest.mark.timeout(400)
+@pytest.mark.parametrize("schedule", ["blocking", "overlap"])
+def test_direct_exchange_equals_all_reduce(tmp_path, schedule):
+    """collective="direct" (delta slices scattered with all_to_all, summed by their owner, gathered back) leaves the same
+    replicas as the all-reduce, bit for bit at two ranks (a + b in either order), blocking and one-window-late; the item
+    table's size is not a multiple of the rank count times anything (zero-padded last slice)."""
+    make_problem(tmp_path, disjoint_items=False, epochs=2)
+    extra = ["-"] if schedule == "blocking" else ["overlap"]
+    a = run_world(tmp_path, "sum", window=48, extra=extra + ["all_reduce"])
+    assert "all_reduce" in str(a[0]["collective"]) and int(a[0]["exchanges"]) > 2
+    a = [{k: r[k].copy() for k in ("iw", "uw")} for r in a]
+    b = run_world(tmp_path, "sum", window=48, extra=extra + ["direct"])
+    assert "all_to_all" in str(b[0]["collective"]) and int(b[0]["exchanges"]) > 2
+    assert np.array_equal(b[0]["iw"], b[1]["iw"])
+    for r in range(2):
+        assert np.array_equal(a[r]["iw"], b[r]["iw"]) and np.array_equal(a[r]["uw"], b[r]["uw"])
+
+
+@pytest.mark.timeout(400)
 def test_mean_sync_averages_replicas(tmp_path):
     clicks, negs, uw, iw, U, N = make_problem(tmp_path, disjoint_items=False, epochs=1)
     T = clicks.shape[0]
