@@ -170,6 +170,46 @@ def test_lightgcn_parser(golden_dir):
     assert indptr.tolist() == [0, 3, 9, 10, 12] and items.tolist() == [3, 4, 7, 0, 1, 2, 3, 5, 6, 9, 2, 8]
 
 
+def test_click_dataset_three_inputs_one_state(tmp_path):
+    """ClickDataset from a LightGCN file (with a user listed twice: first line's position, last line's items,
+    datasets.py:56), from {user: [items]} and from a CSR builds the same interaction list, histories (seeded sample for the
+    long lists, padding for the short ones), lengths, dict, lazily materialised pair list and evaluation CSR."""
+    from heat_amd.cf.cf_config import CFConfig
+    from heat_amd.cf.datasets import ClickDataset
+    rng = np.random.default_rng(3)
+    U, I, H = 40, 300, 6
+    lists = [rng.choice(I, int(rng.integers(1, 15)), replace=False).tolist() for _ in range(U)]
+    path = tmp_path / "train.txt"
+    lines = [f"{u} " + " ".join(map(str, lists[u])) for u in range(U)]
+    lines.insert(5, "17 1 2 3")                      # user 17 appears early with other items: its later line wins
+    path.write_text("\n".join(lines) + "\n")
+    order = [u for u in range(U) if u != 17]
+    order.insert(5, 17)                              # dict order = first occurrence
+    as_dict = {u: lists[u] for u in order}
+    indptr = np.concatenate([[0], np.cumsum([len(x) for x in lists])]).astype(np.uint64)
+    items = np.array([i for x in lists for i in x], dtype=np.uint32)
+    with contextlib.redirect_stdout(io.StringIO()):
+        cfgs = [CFConfig(emb_dim=64, num_negs=4, max_his=H, milestones=[10]) for _ in range(3)]
+        a = ClickDataset(str(path), config=cfgs[0], seed=9, cache=False)
+        b = ClickDataset(config=cfgs[1], seed=9, user_items=as_dict, is_train=True)
+        c = ClickDataset(config=cfgs[2], seed=9, csr=(indptr, items), is_train=True)
+    assert a.user_items_dic == b.user_items_dic and list(a.user_items_dic) == order
+    assert np.array_equal(a.click_dataset, b.click_dataset) and np.array_equal(a.his_items, b.his_items)
+    assert np.array_equal(a.masks, b.masks) and a.user_item_ids == b.user_item_ids == list(map(tuple, a.click_dataset.tolist()))
+    assert a.click_dataset[:len(lists[0])].tolist() == [[0, i] for i in lists[0]]
+    # the CSR lists the users in id order: same per-user state, interaction list in id order
+    assert c.user_items_dic == {u: lists[u] for u in range(U)} and np.array_equal(c.masks, a.masks)
+    short = [u for u in range(U) if len(lists[u]) < H]
+    assert np.array_equal(c.his_items[short], a.his_items[short])
+    for u in range(U):
+        if len(lists[u]) >= H:
+            assert set(c.his_items[u].tolist()) <= set(lists[u]) and len(set(c.his_items[u].tolist())) == H
+    assert (cfgs[0].num_users, cfgs[0].train_size) == (cfgs[2].num_users, cfgs[2].train_size) == (U, sum(map(len, lists)))
+    for ds in (a, b, c):
+        ip, it = ds.train_csr()
+        assert np.array_equal(ip, indptr) and np.array_equal(it, items)
+
+
 def test_yaml_configs_carry_the_reference_keys():
     from heat_amd.cf import utils
     base = os.path.join(ROOT, "heat_amd", "cf", "benchmarks")
