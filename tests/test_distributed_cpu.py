@@ -120,6 +120,22 @@ def test_direct_exchange_equals_all_reduce(tmp_path, schedule):
 
 
 @pytest.mark.timeout(400)
+def test_direct_exchange_three_ranks_padded_slices(tmp_path):
+    """Three ranks: the 200 x 16 table does not divide into three slices (the last one is zero-padded), the owner sums in
+    rank order where gloo's ring sums in ring order — replicas identical within a run, equal to the all-reduce run up to
+    the last bit of a three-term fp32 sum."""
+    make_problem(tmp_path, disjoint_items=False, epochs=2)
+    a = run_world(tmp_path, "sum", window=48, world=3, extra=["overlap", "all_reduce"])
+    a = [{k: r[k].copy() for k in ("iw", "uw")} for r in a]
+    b = run_world(tmp_path, "sum", window=48, world=3, extra=["overlap", "direct"])
+    assert "all_to_all" in str(b[0]["collective"])
+    assert np.array_equal(b[0]["iw"], b[1]["iw"]) and np.array_equal(b[0]["iw"], b[2]["iw"])
+    for r in range(3):
+        np.testing.assert_allclose(b[r]["iw"], a[r]["iw"], rtol=0, atol=2e-6)
+        np.testing.assert_allclose(b[r]["uw"], a[r]["uw"], rtol=0, atol=2e-6)
+
+
+@pytest.mark.timeout(400)
 def test_mean_sync_averages_replicas(tmp_path):
     clicks, negs, uw, iw, U, N = make_problem(tmp_path, disjoint_items=False, epochs=1)
     T = clicks.shape[0]
