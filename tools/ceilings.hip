@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
+#include <cstdlib>
 #include "../heat_amd/csrc/ccl_device.hpp"
 using namespace heatcf;
 
@@ -70,7 +71,7 @@ void run_rows(const char* what, size_t table_bytes, int waves, uint32_t groups_p
     hipFree(table); hipFree(sink);
 }
 
-int main()
+int main(int argc, char** argv)
 {
     {
         const size_t n = (size_t)1 << 27; // 2 GiB of float4
@@ -88,8 +89,10 @@ int main()
         printf("%-58s %8.1f GB/s (read+write bytes)\n", "float4 stream copy, 2 GiB -> 2 GiB", 2.0 * n * 16 / ms / 1e6);
         hipFree(in); hipFree(out);
     }
-    const int waves = 256 * 12;             // what the training kernel keeps resident at AmazonBooks shape
-    const uint32_t gpw = 2048;
+    // waves: argv[1], default 256 * 12 = what the round-1 training kernel kept resident at AmazonBooks shape (round 2: 256 * 8)
+    const int waves = argc > 1 ? atoi(argv[1]) : 256 * 12;
+    const uint32_t gpw = (uint32_t)(2048ull * 256 * 12 / (unsigned)waves);   // same number of rows moved
+    printf("waves = %d\n", waves);
     run_rows<256, false>("random-row gather, Infinity-Cache resident", 47u << 20, waves, gpw);
     run_rows<256, true>("random-row read-modify-write, Infinity-Cache resident", 47u << 20, waves, gpw);
     run_rows<256, false>("random-row gather, HBM resident", (size_t)4000 << 20, waves, gpw);
