@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py — positive-samples/sec of the SimpleX/CCL training hot path on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W]            (N > 1: this process starts the N ranks itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -13,10 +13,12 @@ N = 1  : BASELINE.json configs[1].  Tables and the interaction list are resident
          fraction, where the working set lives, a second roofline object from a short HBM-resident run (configs[4]
          shape, a sample of its interaction list), the same epoch through the reference's own boundary (`cf_c`, host
          buffers written back every epoch: `value_host_mode`) and the CPU oracle timed on this box's host cores.
-N > 1  : BASELINE.json configs[3]: the SAME graph partitioned by user range (cf/main.py:51-57), one shard per rank, item
-         table replicated, item-table deltas all-reduced over RCCL/xGMI while the next window trains
-         (heat_amd.cf.distributed.ItemSync, overlap).  `value` = the graph's interactions x steps / time: strong scaling.
-         Extra keys: the literal "all-reduce every 8192 steps" window, and a short weak-scaling leg (one graph per rank).
+N > 1  : BASELINE.json configs[3]: the SAME graph partitioned by user range (cf/main.py:51-57; ranges cut at equal
+         interaction counts), one shard per rank, item table replicated, item-table deltas all-reduced over RCCL/xGMI
+         (heat_amd.cf.distributed.ItemSync).  Two legs over the same K steps: every exchange completed before the next
+         window (`item_sync_blocking`), then the all-reduce overlapped with the next window — `value` is the second when it
+         finishes (a watchdog falls back to the first).  `value` = the graph's interactions x steps / time: strong scaling.
+         Extra keys: the direct exchange, the literal "all-reduce every 8192 steps" window, a short weak-scaling leg.
 Rank 0 prints ONE JSON line.
 """
 import argparse
@@ -33,7 +35,9 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
 INFINITY_CACHE_BYTES = 256 << 20
-MEASURED_RMW_CEILING_GBS = {"infinity-cache": 8301.9, "hbm": 6185.2}   # profiles/r01_memory_ceilings.txt (256-B rows)
+# bare random-row read-modify-write loop (tools/ceilings.hip, 256-B rows): profiles/r01_memory_ceilings.txt; re-run in round 2
+# (profiles/r02_memory_ceilings.txt) the Infinity-Cache figure is 8.1-8.5 TB/s, the HBM-resident one moves 5.2-6.3 TB/s run to run
+MEASURED_RMW_CEILING_GBS = {"infinity-cache": 8301.9, "hbm": 6185.2}
 
 
 def usable_cpus():
@@ -91,7 +95,9 @@ def roofline(B, B_rd, interactions, kernel_ms, launches, working_set_bytes, traf
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "read_frac": B_rd * per_launch / per_launch_s / 1e9 / HBM_PEAK_GBS,
             "measured_ceiling": ceiling, "frac_of_measured_ceiling": achieved / ceiling,
-            "measured_ceiling_source": "profiles/r01_memory_ceilings.txt: random-row read-modify-write, same residency",
+            "measured_ceiling_source": "profiles/r02_memory_ceilings.txt (first measured in r01_memory_ceilings.txt): bare random-row "
+                                       "read-modify-write loop, same residency; band across runs 8.1-8.5 TB/s (Infinity Cache), "
+                                       "5.2-6.3 TB/s (HBM)",
             "traffic": traffic, "traffic_unit": "GB per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)", "traffic_source": traffic_source,
             "residency": "infinity-cache" if resident else "hbm",
             "working_set_mb": working_set_bytes / 1e6,
@@ -173,7 +179,7 @@ def tile_sampler_leg(clicks_t, n, uw_h, iw_h, dev, stream, U, I, d, N, steps):
     user_w = torch.from_numpy(uw_h).to(dev)
     item_w = torch.from_numpy(iw_h).to(dev)
     out = {}
-    for name, extra in (("in_lds", 0), ("in_global_memory", abi.FLAG_TILE_GLOBAL)):
+    for name, extra in (("in_lds", abi.FLAG_TILE_LDS), ("in_global_memory", 0)):
         eng = abi.Engine.from_device(clicks_t.data_ptr(), n, user_w.data_ptr(), item_w.data_ptr(), num_users=U, num_items=I,
                                      emb_dim=d, num_negs=N, stream=stream, keep=(clicks_t, user_w, item_w), seed=2022,
                                      neg_sampler=1, tile_size=512, refresh_interval=8192, flags=abi.FLAG_SAMPLING_CALL | extra)
@@ -191,8 +197,8 @@ def tile_sampler_leg(clicks_t, n, uw_h, iw_h, dev, stream, U, I, d, N, steps):
         out[name] = {"value": n * steps / dt, "unit": "samples/s", "kernel_ms_per_launch": kernel_ms / max(launches, 1),
                      "kernel": eng.kernel_name}
         eng.close()
-    out["note"] = ("random-tile sampler (tile 512, refresh 8192, sampling() call): tile deltas resident in LDS (12 streams per "
-                   "workgroup, flushed by float atomics at the end of the launch) vs every step written to the table")
+    out["note"] = ("random-tile sampler (tile 512, refresh 8192, sampling() call): tile deltas resident in LDS (opt-in, 12 streams "
+                   "per workgroup, flushed by float atomics at the end of the launch) vs every step written to the table (default)")
     return out
 
 
@@ -254,6 +260,35 @@ def host_mode_leg(graph, d, N, steps, pinned):
     return T * steps / dt
 
 
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def self_launch(n, argv, runner=None):
+    """Start `n` ranks of this script under torch.distributed.run (one per GPU, rendezvous on 127.0.0.1), relay the ONE
+    JSON line rank 0 prints and return the children's exit code.  `runner` (tests) replaces subprocess.run."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: what RCCL needs on this driver
+    env.setdefault("OMP_NUM_THREADS", "4")
+    res = (runner or subprocess.run)(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in (res.stdout or "").splitlines() if ln.startswith("{") and '"metric"' in ln]
+    for ln in (res.stdout or "").splitlines():
+        if ln not in lines:
+            print(ln, file=sys.stderr)                       # whatever else the ranks wrote to stdout is not the result
+    if lines:
+        print(lines[-1], flush=True)
+    if res.returncode == 0 and not lines:
+        print("bench.py launcher: the ranks exited 0 without a result line", file=sys.stderr)
+        return 1
+    return res.returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -266,24 +301,32 @@ def main():
     ap.add_argument("--no-overlap", action="store_true", help="N>1: complete every exchange before the next window")
     ap.add_argument("--collective", default=os.environ.get("HEAT_BENCH_COLLECTIVE", "all_reduce"), choices=("all_reduce", "direct"),
                     help="N>1: how the item-table deltas are summed over the ranks (heat_amd.cf.distributed.ItemSync)")
+    ap.add_argument("--balance", default="interactions", choices=("interactions", "users"),
+                    help="N>1: cut the user ranges at equal interaction counts (default) or equal user counts (cf/main.py:51-57)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the HBM-resident, host-mode, literal-window and weak-scaling legs")
     ap.add_argument("--interactions", type=int, default=0,
                     help="interactions per step for --shape synthetic_hbm (0 = 20 000 000: a sample of the 200 M list)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python3 bench.py --gpus N` by itself: this process becomes the launcher (cf/main.py:47-70 is started by mpirun; here
+        # one rank per GPU under torch.distributed.run).  Nothing in this process has touched torch or HIP yet, and it
+        # never will: the ranks are CHILDREN, their rank 0's JSON line is relayed, their exit code is this one's.
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
+
     import torch
     import torch.distributed as dist
     from heat_amd import abi
     from heat_amd.cf import synthetic
-    from heat_amd.cf.distributed import ItemSync, shard_bounds, shard_clicks
+    from heat_amd.cf.distributed import ItemSync, shard_bounds, shard_bounds_balanced, shard_clicks
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        sys.exit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start `python bench.py --gpus N` by itself or under "
+                 f"torch.distributed.run --nproc-per-node N")
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X (no CPU fallback)")
     abi.load()
@@ -376,42 +419,126 @@ def main():
     else:
         graph = synthetic.make_graph(U, I, T, seed=2022, with_test=False)       # ONE graph, the same on every rank
         uw_h, iw_h = synthetic.init_embeddings(U, I, d, seed=2022)
-        lo, hi = shard_bounds(U, world, rank)                                   # cf/main.py:51-57 (rank 0 fixed)
+        by_users = [shard_bounds(U, world, r) for r in range(world)]            # cf/main.py:51-57 (rank 0 fixed)
+        by_work = [shard_bounds_balanced(graph.train_indptr, world, r) for r in range(world)]
+        # The slowest rank sets the epoch: ranges are cut at equal INTERACTION counts ("build may balance ranges
+        # by interaction prefix-sum"), --balance users restores the reference's equal user counts
+        all_bounds = by_users if args.balance == "users" else by_work
+        lo, hi = all_bounds[rank]
         shard, lo, hi = shard_clicks(graph.clicks, U, world, rank, bounds=(lo, hi))
         base = int(np.searchsorted(graph.clicks[:, 0], lo, side="left"))
         eng, item_w = build(shard, hi - lo, uw_h[lo:hi], base, None)
-        my_T, total_T, scaling = shard.shape[0], T, ("strong" if world > 1 else "weak")
+        my_T, total_T, scaling = shard.shape[0], T, ("strong" if world > 1 else "n/a")
         workload = (f"{args.shape}-shaped synthetic graph: {U} users x {I} items, {T} interactions, d={d}, negs={N}, uniform "
                     f"on-GPU Philox sampler; 1 step = 1 epoch" +
-                    (f"; user rows partitioned over {world} GPUs (cf/main.py:51-57), item table replicated" if world > 1 else ""))
+                    (f"; user rows partitioned over {world} GPUs (cf/main.py:51-57; ranges cut at equal "
+                     f"{'user' if args.balance == 'users' else 'interaction'} counts), item table replicated" if world > 1 else ""))
         working_set = 2 * ((hi - lo) + I) * d * 4
-        trainer = None
-        if world > 1 or force_sync:
-            # default exchange schedule: 2 windows per epoch, every all-reduce overlapped with the next window (also across
-            # the epoch boundary); the pipeline is drained inside the timed region
-            trainer = ItemSync(eng, item_w, world, windows_per_epoch=args.windows or 2, mode="sum",
-                               force_collective=force_sync, overlap=not args.no_overlap, defer_final=not args.no_overlap,
-                               collective=args.collective)
+        if world > 1:
+            tp = graph.train_indptr.astype(np.int64)
+            extra["shards"] = {"balance": args.balance,
+                               "interactions_per_rank": [int(tp[b] - tp[a]) for a, b in all_bounds],
+                               "users_per_rank": [int(b - a) for a, b in all_bounds],
+                               "interactions_per_rank_if_cut_by_user_count": [int(tp[b] - tp[a]) for a, b in by_users]}
 
-    def step():
-        if trainer is None:
-            eng.begin_epoch()
-            eng.train_range(0, my_T, want_loss=False)
-            eng.end_epoch()
-        else:
-            trainer.train_one_epoch()
+    def step_plain():
+        eng.begin_epoch()
+        eng.train_range(0, my_T, want_loss=False)
+        eng.end_epoch()
 
-    finish = trainer.finalize if trainer is not None else None
-    for _ in range(args.warmup):
-        step()
-    if finish:
-        finish()
-    fence()
-    eng.kernel_time(reset=True)
-    elapsed = timed(step, args.steps, 0, finish)
-    kernel_ms, launches = eng.kernel_time()
+    def sync_kwargs(overlap):
+        return dict(windows_per_epoch=args.windows or 2, mode="sum", force_collective=force_sync, overlap=overlap,
+                    defer_final=overlap, collective=args.collective)
+
+    def line(value_elapsed, steps, trainer, kernel_ms, launches, note=None):
+        traffic, traffic_src = (None, None)
+        if world == 1 and args.shape in ("amazonbooks", "yelp18") and args.update_mode == 0 and args.num_streams == 0:
+            traffic, traffic_src = replayed_traffic("r02_pmc_traffic.json" if args.shape == "amazonbooks" else
+                                                    "r02_pmc_traffic_yelp18.json", eng.kernel_name)
+        out = {
+            "metric": "positive-samples/sec/node (AmazonBooks d=64, negs=16)" if args.shape == "amazonbooks"
+            else f"positive-samples/sec/node ({args.shape} d={d}, negs={N})",
+            "value": total_T * steps / value_elapsed,
+            "unit": "samples/s",
+            "n_gpus": world,
+            "steps": steps,
+            "warmup": args.warmup,
+            "ms_per_step": value_elapsed / steps * 1e3,
+            "higher_is_better": True,
+            "scaling": scaling,
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": workload, "kernel": eng.kernel_name,
+                       "item_sync": None if trainer is None else trainer.describe()},
+            # rank 0's training kernel: its shard's interactions over its HIP-event time
+            "roofline": roofline(B, B_rd, my_T * steps, kernel_ms, launches, working_set, traffic, traffic_src),
+        }
+        if note:
+            out["note"] = note
+        return out
+
+    def guard(limit, fallback_line):
+        """Watchdog for a leg built on collectives nobody has run on this node yet: if it is still going after `limit`
+        seconds every rank leaves (same timer on every rank) and rank 0 prints what it already has."""
+        import threading
+
+        def bail():
+            if rank == 0:
+                out = fallback_line()
+                out.update(extra)
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+
+        t = threading.Timer(limit, bail)
+        t.daemon = True
+        t.start()
+        return t
+
+    trainer = None
+    if args.shape != "synthetic_hbm" and (world > 1 or force_sync):
+        # N > 1, two legs over the same K steps.  First the schedule that completes every exchange before the next window
+        # starts (blocking collective: nothing of it has ever been in doubt).  Then the default schedule — the all-reduce of
+        # a window overlapped with the next window, also across the epoch boundary, the pipeline drained inside the timed
+        # region — under a watchdog: should the overlapped collectives not finish on this node, every rank leaves and rank 0
+        # reports the blocking leg instead of nothing.
+        blocking = ItemSync(eng, item_w, world, **sync_kwargs(False))
+        for _ in range(args.warmup):
+            blocking.train_one_epoch()
+        fence()
+        eng.kernel_time(reset=True)
+        el_b = timed(blocking.train_one_epoch, args.steps, 0, None)
+        kms_b, ln_b = eng.kernel_time()
+        extra["item_sync_blocking"] = {"value": total_T * args.steps / el_b, "unit": "samples/s", "ms_per_step": el_b / args.steps * 1e3,
+                                       "steps": args.steps, "item_sync": blocking.describe()}
+        trainer, elapsed, kernel_ms, launches = blocking, el_b, kms_b, ln_b
+        if not args.no_overlap:
+            limit = float(os.environ.get("HEAT_BENCH_WATCHDOG_S", "0")) or max(90.0, 30.0 * el_b + 60.0)
+            dog = guard(limit, lambda: line(el_b, args.steps, blocking, kms_b, ln_b,
+                                            note=f"the overlapped schedule did not finish within {limit:.0f} s: `value` is "
+                                                 f"the blocking schedule"))
+            over = ItemSync(eng, item_w, world, **sync_kwargs(True))
+            for _ in range(min(args.warmup, 2)):
+                over.train_one_epoch()
+            over.finalize()
+            fence()
+            eng.kernel_time(reset=True)
+            el_o = timed(over.train_one_epoch, args.steps, 0, over.finalize)
+            kms_o, ln_o = eng.kernel_time()
+            dog.cancel()
+            trainer, elapsed, kernel_ms, launches = over, el_o, kms_o, ln_o
+    else:
+        for _ in range(args.warmup):
+            step_plain()
+        fence()
+        eng.kernel_time(reset=True)
+        elapsed = timed(step_plain, args.steps, 0, None)
+        kernel_ms, launches = eng.kernel_time()
 
     if world > 1 and not args.no_extra_legs and trainer is not None:
+        head = (elapsed, trainer, kernel_ms, launches)
+        dog = guard(float(os.environ.get("HEAT_BENCH_WATCHDOG_S", "0")) or 240.0,
+                    lambda: line(head[0], args.steps, head[1], head[2], head[3], note="an extra leg did not finish: cut short"))
         # (a) the literal reading of configs[3]: one all-reduce every 8192 interactions per GPU
         lit = ItemSync(eng, item_w, world, sync_interactions=8192, mode="sum", overlap=not args.no_overlap,
                        defer_final=not args.no_overlap)
@@ -442,31 +569,10 @@ def main():
                                  "workload": f"one {args.shape}-shaped graph PER GPU ({world} x {T} interactions per step)",
                                  "item_sync": tr2.describe()}
         eng2.close()
+        dog.cancel()
 
     if rank == 0:
-        traffic, traffic_src = (None, None)
-        if world == 1 and args.shape in ("amazonbooks", "yelp18") and args.update_mode == 0 and args.num_streams == 0:
-            traffic, traffic_src = replayed_traffic("r02_pmc_traffic.json" if args.shape == "amazonbooks" else
-                                                    "r02_pmc_traffic_yelp18.json", eng.kernel_name)
-        out = {
-            "metric": "positive-samples/sec/node (AmazonBooks d=64, negs=16)" if args.shape == "amazonbooks"
-            else f"positive-samples/sec/node ({args.shape} d={d}, negs={N})",
-            "value": total_T * args.steps / elapsed,
-            "unit": "samples/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True,
-            "scaling": scaling,
-            "vs_baseline": None,
-            "dtype": "f32",
-            "data": "synthetic",
-            "config": {"workload": workload, "kernel": eng.kernel_name,
-                       "item_sync": None if trainer is None else trainer.describe()},
-            # rank 0's training kernel: its shard's interactions over its HIP-event time
-            "roofline": roofline(B, B_rd, my_T * args.steps, kernel_ms, launches, working_set, traffic, traffic_src),
-        }
+        out = line(elapsed, args.steps, trainer, kernel_ms, launches)
         out.update(extra)
         if world == 1 and not args.no_extra_legs:
             k = max(2, min(10, args.steps))

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("HEAT_CF_LIB") or os.path.join(HERE, "lib", "libheat_cf.so")   # HEAT_CF_LIB: development builds
 
 OK, EINVAL, EHIP, ENOMEM, EUNSUP = 0, -1, -2, -3, -4
-FLAG_SERIAL, FLAG_LAZY_SYNC, FLAG_SAMPLING_CALL, FLAG_NULL_STREAM, FLAG_TILE_GLOBAL = 0x1, 0x2, 0x4, 0x8, 0x10
+FLAG_SERIAL, FLAG_LAZY_SYNC, FLAG_SAMPLING_CALL, FLAG_NULL_STREAM, FLAG_TILE_GLOBAL, FLAG_TILE_LDS = 0x1, 0x2, 0x4, 0x8, 0x10, 0x20
 COHERENCE_DEFAULT, COHERENCE_PLAIN, COHERENCE_DEVICE = 0, 1, 2
 UPDATE_DEFAULT, UPDATE_OVERWRITE, UPDATE_ATOMIC_W, UPDATE_ATOMIC_WG, UPDATE_ATOMIC_POS, UPDATE_AUTO, UPDATE_REREAD_POS = 0, 1, 2, 3, 4, 5, 6
 

@@ -79,7 +79,7 @@ class ClickDataset(Dataset):
             users = np.fromiter((int(u) for u in user_items), dtype=np.int64, count=len(user_items))
             lens = np.fromiter((len(v) for v in user_items.values()), dtype=np.int64, count=len(user_items))
             items_all = np.fromiter((int(i) for v in user_items.values() for i in v), dtype=np.uint64, count=int(lens.sum()))
-            starts = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int64)
+            starts = (np.cumsum(lens) - lens).astype(np.int64)          # exclusive prefix sum (length 0 for an empty dict)
         tolist = items_all.tolist()
         self.user_items_dic = {int(u): tolist[a:a + n] for u, a, n in zip(users.tolist(), starts.tolist(), lens.tolist())}
         # datasets.py:44-45: one history row per line, indexed by user id (sized by the largest id so that a file
@@ -101,7 +101,7 @@ class ClickDataset(Dataset):
             self.his_items[u] = rnd.sample(tolist[a:a + n], self.max_his)
             self.masks[u] = self.max_his
         # :74-78 interactions in dict order
-        take = np.repeat(starts - np.concatenate([[0], np.cumsum(lens)[:-1]]), lens) + np.arange(int(lens.sum()), dtype=np.int64)
+        take = np.repeat(starts - (np.cumsum(lens) - lens), lens) + np.arange(int(lens.sum()), dtype=np.int64)
         self._clicks = np.stack([np.repeat(users.astype(np.uint64), lens), items_all[take]], axis=1) if users.size else \
             np.zeros((0, 2), dtype=np.uint64)
         self._pairs = None

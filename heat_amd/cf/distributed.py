@@ -148,11 +148,14 @@ class ItemSync:
         if self.native:
             self.engine.sync_apply(self.ref.data_ptr(), self.sum.data_ptr(), self.mine.data_ptr() if with_mine else 0, self.scale)
         elif with_mine:
+            # the expressions of item_apply_kernel, operation by operation (item_sync.hip is built without FMA contraction):
+            # s = scale * sum; W = W + (s - mine); ref = ref + s
             self.sum.mul_(self.scale)
-            self.item_w.add_(self.sum).sub_(self.mine)
+            self.item_w.add_(self.sum - self.mine)
             self.ref.add_(self.sum)
         else:
-            self.ref.add_(self.sum, alpha=self.scale)
+            self.sum.mul_(self.scale)             # item_apply_exact_kernel: W = ref = ref + scale * sum
+            self.ref.add_(self.sum)
             self.item_w.copy_(self.ref)
 
     def _complete(self):

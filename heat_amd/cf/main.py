@@ -113,7 +113,9 @@ def main(argv=None):
                          update_mode=int(model_config.get('update_mode', 0)),
                          # `sampling_call: true` = the loop's alternative sampler call (train/engine.cpp:333): the only one in
                          # which neg_sampler 1 draws from its tile (random_tile_negative_sampler.cpp:23-45 vs :47-57)
-                         flags=4 if model_config.get('sampling_call', False) else 0)
+                         # `tile_in_lds: true` (with sampling_call): hold the tile's weight deltas in LDS where they fit (opt-in)
+                         flags=(4 if model_config.get('sampling_call', False) else 0) |
+                               (0x20 if model_config.get('tile_in_lds', False) else 0))
     print('--- Start loading data ---')
     if args.synthetic:
         graph, _, _ = synthetic.make_named(args.synthetic, seed=seed, scale=args.scale)

@@ -87,7 +87,8 @@ struct heat_cf_engine
     uint32_t cu_count = 256;
     uint32_t auto_streams = 1;
     bool     tile_resident = false; // random-tile sampler with the tile's weight deltas held in LDS (ccl_train.hip, TS > 1)
-    char     kname[96] = {0};
+    char     kbase[96] = {0};       // variant / policy / streams
+    char     kname[112] = {0};      // kbase + what the LAST launch actually ran (tile-in-lds or not)
     // timing
     std::vector<EventPair> ev_free, ev_pending;
     double   kernel_ms = 0.0;
@@ -223,10 +224,13 @@ int make_plan(const heat_cf_config* cfg, uint64_t data_rows, uint64_t fill, Plan
     return HEAT_CF_OK;
 }
 
-// the random-tile sampler keeps its tile in LDS when this holds (ccl_train.hip, TS > 1)
+// the random-tile sampler keeps its tile in LDS when the caller asks for it (HEAT_CF_FLAG_TILE_LDS) and this
+// holds (ccl_train.hip, TS > 1).  Opt-in since round 3: a tile shared by the 12 streams of a workgroup, with its negative-row
+// weight updates private to that workgroup until the end of the launch, is a different sampler regime from the reference's
+// one tile per worker written through to the table (DESIGN.md section 3 "Tile in LDS").
 bool tile_fits_lds(const heat_cf_config* cfg, const Plan& p)
 {
-    return cfg->neg_sampler == 1 && (cfg->flags & HEAT_CF_FLAG_SAMPLING_CALL) &&
+    return cfg->neg_sampler == 1 && (cfg->flags & HEAT_CF_FLAG_SAMPLING_CALL) && (cfg->flags & HEAT_CF_FLAG_TILE_LDS) &&
            !(cfg->flags & (HEAT_CF_FLAG_SERIAL | HEAT_CF_FLAG_TILE_GLOBAL)) && p.nw == 1 && p.lpr <= 16 && p.ng <= 4 &&
            !cfg->use_aggregator && p.upd_bits == 0xCu && p.coherence == HEAT_CF_COHERENCE_DEVICE &&
            cfg->tile_size <= 0xFFFFFFFFull && cfg->tile_size * cfg->emb_dim * sizeof(float) <= 128u * 1024u;
@@ -286,8 +290,12 @@ int common_init(heat_cf_engine* e, const heat_cf_config* cfg, uint64_t data_rows
     // with the random-tile sampler (its sampling() call) the tile lives in LDS when it fits: 12 single-wave
     // streams per workgroup share tile_size x emb_dim fp32 of accumulated weight deltas (<= 128 KB)
     e->tile_resident = tile_fits_lds(cfg, plan);
-    std::snprintf(e->kname, sizeof(e->kname), "ccl_train_kernel<%d,%d,%d,%d>/upd=0x%x/streams=%u%s", e->lpr, e->ng, e->aux, e->nw,
-                  (unsigned)e->upd, (unsigned)plan.streams, e->tile_resident ? "/tile-in-lds" : "");
+    std::snprintf(e->kbase, sizeof(e->kbase), "ccl_train_kernel<%d,%d,%d,%d>/upd=0x%x/streams=%u", e->lpr, e->ng, e->aux, e->nw,
+                  (unsigned)e->upd, (unsigned)plan.streams);
+    // until a launch says otherwise the name carries the plan; heat_cf_train_range rewrites it with what it launched (a
+    // tile-resident engine falls back to the table-writing kernel for caller-fed negatives and for windows longer than
+    // refresh_interval calls per stream)
+    std::snprintf(e->kname, sizeof(e->kname), "%s%s", e->kbase, e->tile_resident ? "/tile-in-lds" : "");
     HIP_TRY(hipMalloc(&e->d_sums, 2 * sizeof(double)));
     HIP_TRY(hipMemsetAsync(e->d_sums, 0, 2 * sizeof(double), e->stream));
     HIP_TRY(hipMalloc(&e->d_stats, 4 * sizeof(uint32_t)));
@@ -672,20 +680,21 @@ int heat_cf_train_range(heat_cf_engine* e, uint64_t begin, uint64_t end, const u
         launch_grid = (grid + (uint32_t)TILE_STREAMS - 1) / (uint32_t)TILE_STREAMS;
         loss_slots = launch_grid * (uint32_t)TILE_STREAMS;
     }
+    if (e->tile_resident) std::snprintf(e->kname, sizeof(e->kname), "%s%s", e->kbase, resident ? "/tile-in-lds" : "");
     int rc = ensure_loss_part(e, loss_slots);
     if (rc) return rc;
-    if (e->cfg.use_aggregator && loss_slots > e->agg_state_cap)
+    if (e->cfg.use_aggregator && !e->d_agg_state)
     {
-        // first launch (or a larger grid than any before): fresh, zeroed state — within an epoch the grid of a later
-        // window is never larger than the first one's
-        HIP_TRY(hipStreamSynchronize(e->stream));
-        if (e->d_agg_state) HIP_TRY(hipFree(e->d_agg_state));
-        e->d_agg_state = nullptr;
-        const size_t bytes = (size_t)loss_slots * agg_state_floats(e->lpr) * sizeof(float);
+        // per-stream aggregator state (call counter + pairs not yet applied), sized ONCE for the largest grid any range can
+        // produce (geometry() never launches more than auto_streams workgroups): a later, larger window of the same epoch
+        // must not find its predecessors' counters reallocated away
+        const size_t cap = std::max<size_t>(e->auto_streams, 1);
+        const size_t bytes = cap * agg_state_floats(e->lpr) * sizeof(float);
         HIP_TRY(hipMalloc(&e->d_agg_state, bytes));
         HIP_TRY(hipMemsetAsync(e->d_agg_state, 0, bytes, e->stream));
-        e->agg_state_cap = loss_slots;
+        e->agg_state_cap = cap;
     }
+    if (e->cfg.use_aggregator && loss_slots > e->agg_state_cap) return fail(HEAT_CF_EINVAL, "internal: grid exceeds the aggregator state");
     TrainArgs a = make_args(e, begin, end);
     a.per_block = per_block;
     a.tile_streams = resident ? (uint32_t)TILE_STREAMS : 0u;

@@ -44,9 +44,14 @@ extern "C" {
 #define HEAT_CF_FLAG_LAZY_SYNC     0x2u /* host mode: do not write weights back after every epoch              */
 #define HEAT_CF_FLAG_NULL_STREAM   0x8u /* device mode with stream == NULL: launch on the legacy default stream instead of
                                            creating a private non-blocking one (callers whose other work is there)   */
-#define HEAT_CF_FLAG_TILE_GLOBAL   0x10u /* random-tile sampler: do NOT hold the tile in LDS (default when it fits: 12 streams per
-                                           workgroup share tile_size x emb_dim fp32 of accumulated weight deltas, flushed to
-                                           the table by float atomics at the end of the launch)                          */
+#define HEAT_CF_FLAG_TILE_GLOBAL   0x10u /* random-tile sampler: never hold the tile in LDS (the default since round 3; the flag
+                                           still wins over HEAT_CF_FLAG_TILE_LDS)                                        */
+#define HEAT_CF_FLAG_TILE_LDS      0x20u /* random-tile sampler (with HEAT_CF_FLAG_SAMPLING_CALL): hold the tile in LDS when it
+                                           fits — 12 streams per workgroup share tile_size x emb_dim fp32 of accumulated
+                                           weight deltas, flushed to the table by float atomics at the end of the launch.
+                                           Opt-in: the tile is then shared by 12 streams and its negative-row updates are
+                                           private to the workgroup for the launch, unlike the reference's one tile per
+                                           worker written through to the table                                          */
 #define HEAT_CF_FLAG_SAMPLING_CALL 0x4u /* use sampler.sampling() (engine.cpp:333) instead of the live
                                            ignore_pos_sampling() (engine.cpp:332)                              */
 

@@ -210,6 +210,18 @@ def test_click_dataset_three_inputs_one_state(tmp_path):
         assert np.array_equal(ip, indptr) and np.array_equal(it, items)
 
 
+def test_click_dataset_from_an_empty_dict():
+    """An empty split (e.g. a test file without lines) builds an empty dataset instead of raising (round-2 regression)."""
+    from heat_amd.cf.cf_config import CFConfig
+    from heat_amd.cf.datasets import ClickDataset
+    with contextlib.redirect_stdout(io.StringIO()):
+        ds = ClickDataset(config=CFConfig(emb_dim=64, num_negs=4, max_his=6, milestones=[10]), user_items={}, is_train=False)
+        one = ClickDataset(config=CFConfig(emb_dim=64, num_negs=4, max_his=6, milestones=[10]), user_items={0: [1, 2], 3: []},
+                           is_train=False)
+    assert ds.user_item_ids == [] and ds.user_items_dic == {} and ds.his_items.shape[0] == 0
+    assert one.user_item_ids == [(0, 1), (0, 2)] and one.masks[:, 0].tolist() == [2, 0, 0, 0]
+
+
 def test_yaml_configs_carry_the_reference_keys():
     from heat_amd.cf import utils
     base = os.path.join(ROOT, "heat_amd", "cf", "benchmarks")
@@ -283,11 +295,13 @@ def test_launch_plan_host_logic():
     assert p["streams"] == 3017 and p["update_mode"] == "ATOMIC_POS" and p["update_bits"] == 0xC and p["coherence"] == "device"
     # random-tile sampler (its sampling() call): the tile's weight deltas live in LDS where tile_size x emb_dim x 4 B <= 128 KB
     T_ = dict(A, neg_sampler=1, tile_size=512, refresh_interval=8192)
-    assert abi.plan(flags=abi.FLAG_SAMPLING_CALL, **T_)["tile_in_lds"] is True
-    assert abi.plan(**T_)["tile_in_lds"] is False                                          # ignore_pos_sampling never uses the tile
-    assert abi.plan(flags=abi.FLAG_SAMPLING_CALL | abi.FLAG_TILE_GLOBAL, **T_)["tile_in_lds"] is False
-    assert abi.plan(flags=abi.FLAG_SAMPLING_CALL, **dict(T_, tile_size=1024))["tile_in_lds"] is False   # 256 KB
-    assert abi.plan(flags=abi.FLAG_SAMPLING_CALL, emb_dim=128, num_negs=64, num_users=31668, num_items=38048,
+    LDS = abi.FLAG_SAMPLING_CALL | abi.FLAG_TILE_LDS
+    assert abi.plan(flags=LDS, **T_)["tile_in_lds"] is True
+    assert abi.plan(flags=abi.FLAG_SAMPLING_CALL, **T_)["tile_in_lds"] is False            # opt-in since round 3
+    assert abi.plan(flags=abi.FLAG_TILE_LDS, **T_)["tile_in_lds"] is False                 # ignore_pos_sampling never uses the tile
+    assert abi.plan(flags=LDS | abi.FLAG_TILE_GLOBAL, **T_)["tile_in_lds"] is False
+    assert abi.plan(flags=LDS, **dict(T_, tile_size=1024))["tile_in_lds"] is False   # 256 KB
+    assert abi.plan(flags=LDS, emb_dim=128, num_negs=64, num_users=31668, num_items=38048,
                     train_size=1237259, neg_sampler=1, tile_size=512)["tile_in_lds"] is False           # multi-wave variant
     # fewer resident workgroups than the cap: the chip is the limit
     assert abi.plan(resident_workgroups=1024, **A)["streams"] == 1024

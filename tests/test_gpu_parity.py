@@ -333,7 +333,7 @@ def test_tile_in_lds_single_stream_equals_tile_in_global_memory():
     uw = (rng.standard_normal((U, d)) * 0.1).astype(np.float32)
     iw = (rng.standard_normal((I, d)) * 0.1).astype(np.float32)
     out = {}
-    for name, extra in (("lds", 0), ("global", abi.FLAG_TILE_GLOBAL)):
+    for name, extra in (("lds", abi.FLAG_TILE_LDS), ("global", 0)):
         a, b = uw.copy(), iw.copy()
         eng = abi.Engine(clicks, a, b, num_negs=N, seed=seed, neg_sampler=1, tile_size=tile, refresh_interval=100000, num_streams=1,
                          update_mode=abi.UPDATE_ATOMIC_POS, flags=abi.FLAG_SAMPLING_CALL | extra)
@@ -364,8 +364,8 @@ def test_tile_in_lds_recall_ndcg_amazonbooks_shape():
     for seed in (2022, 7, 99):     # means over three seeds: one configuration run twice differs by up to 8e-4 in Recall@20
         uw0, iw0 = synthetic.init_embeddings(g.num_users, g.num_items, d, seed=seed)
         for name, kw in (("uniform", dict()),
-                         ("tile-global", dict(neg_sampler=1, tile_size=512, refresh_interval=8192, flags=abi.FLAG_SAMPLING_CALL | abi.FLAG_TILE_GLOBAL | abi.FLAG_LAZY_SYNC)),
-                         ("tile-lds", dict(neg_sampler=1, tile_size=512, refresh_interval=8192, flags=abi.FLAG_SAMPLING_CALL | abi.FLAG_LAZY_SYNC))):
+                         ("tile-global", dict(neg_sampler=1, tile_size=512, refresh_interval=8192, flags=abi.FLAG_SAMPLING_CALL | abi.FLAG_LAZY_SYNC)),
+                         ("tile-lds", dict(neg_sampler=1, tile_size=512, refresh_interval=8192, flags=abi.FLAG_SAMPLING_CALL | abi.FLAG_TILE_LDS | abi.FLAG_LAZY_SYNC))):
             kw.setdefault("flags", abi.FLAG_LAZY_SYNC)
             uw, iw = uw0.copy(), iw0.copy()
             eng = abi.Engine(g.clicks, uw, iw, num_negs=N, seed=seed, **kw)
@@ -858,6 +858,58 @@ def test_device_mode_engine_with_item_sync_on_a_side_stream():
     res = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "_gpu_sync_worker.py")],
                          env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
     assert res.returncode == 0 and "SYNC_OK" in res.stdout, res.stdout[-3000:]
+
+
+def test_item_sync_kernels_equal_the_torch_arithmetic_bit_for_bit():
+    """heat_cf_sync_delta / heat_cf_sync_apply (item_sync.hip) against the torch arithmetic ItemSync falls back to without a
+    HIP engine (heat_amd/cf/distributed.py: _delta, _apply) on the same tensors: bit for bit, with `mine` NULL (blocking
+    exchange: W = ref = ref + scale * sum) and non-NULL (overlapped exchange: W += scale * sum - mine), scale 1 and 1/3."""
+    import torch
+    from heat_amd.cf.distributed import ItemSync
+    dev = torch.device("cuda", 0)
+    d, U, I, T = 64, 6, 1237, 64
+    g = torch.Generator(device=dev)
+    g.manual_seed(7)
+    clicks = torch.zeros((T, 2), dtype=torch.int64, device=dev)
+    uw = torch.zeros((U, d), device=dev)
+
+    class Plain:                  # an engine without the fused passes: ItemSync then runs the torch expressions
+        data_rows = T
+
+    for scale_mode, world in (("sum", 2), ("mean", 3)):
+        for with_mine in (False, True):
+            w0 = torch.randn((I, d), device=dev, generator=g) * 0.1
+            ref0 = w0 + torch.randn((I, d), device=dev, generator=g) * 1e-3
+            others = torch.randn((I, d), device=dev, generator=g) * 1e-3          # what the other ranks would add to the sum
+            trained = torch.randn((I, d), device=dev, generator=g) * 1e-3         # progress made while the exchange was in flight
+            w_n, w_t = w0.clone(), w0.clone()
+            eng = abi.Engine.from_device(clicks.data_ptr(), T, uw.data_ptr(), w_n.data_ptr(), num_users=U, num_items=I, emb_dim=d,
+                                         num_negs=4, keep=(clicks, uw, w_n))
+            nat = ItemSync(eng, w_n, world, mode=scale_mode, overlap=with_mine, dist=object())
+            ref = ItemSync(Plain(), w_t, world, mode=scale_mode, overlap=with_mine, dist=object())
+            assert nat.native and not ref.native
+            for s_ in (nat, ref):
+                s_.ref.copy_(ref0)
+            torch.cuda.synchronize()
+            nat._delta(with_mine)
+            ref._delta(with_mine)
+            eng.synchronize()
+            torch.cuda.synchronize()
+            assert torch.equal(nat.sum, ref.sum) and (not with_mine or torch.equal(nat.mine, ref.mine))
+            for s_, w_ in ((nat, w_n), (ref, w_t)):
+                s_.sum.add_(others)                                                # "all-reduce"
+                if with_mine:
+                    w_.add_(trained)
+            torch.cuda.synchronize()
+            nat._apply(with_mine)
+            ref._apply(with_mine)
+            eng.synchronize()
+            torch.cuda.synchronize()
+            assert torch.equal(w_n, w_t) and torch.equal(nat.ref, ref.ref), (scale_mode, with_mine)
+            assert not torch.equal(w_n, w0)
+            if not with_mine:
+                assert torch.equal(w_n, nat.ref)                                   # blocking form: replicas identical
+            eng.close()
 
 
 def test_edge_shapes_empty_single_tiny():

@@ -1,6 +1,7 @@
 # Round-end evidence run (GPU box): the bench line, rocprofv3 kernel stats and the two PMC passes for the same command,
 # the HBM-resident shape likewise, other shapes.  Outputs under gpurun_out/final/ ; copy what is judged into profiles/.
-mkdir -p gpurun_out/final && cd "$(dirname "$0")/.." && export TMPDIR=/tmp
+set -u
+cd "$(dirname "$0")/.." && rm -rf gpurun_out/final && mkdir -p gpurun_out/final && export TMPDIR=/tmp   # a fresh directory: collect_profiles.sh must never find an earlier run's files
 o=gpurun_out/final
 timeout -k 10 300 python bench.py > $o/bench_n1.json 2> $o/bench.err; echo "bench rc=$?"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $o/prof -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extra-legs > $o/bench_under_rocprof.json 2> $o/prof.err; echo "prof rc=$?"
