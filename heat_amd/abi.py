@@ -64,6 +64,9 @@ SYMBOLS = {
     "heat_cf_synchronize": (C.c_int, [C.c_void_p]),
     "heat_cf_sync_delta": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "heat_cf_sync_apply": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float]),
+    "heat_cf_sync_apply_snap": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "heat_cf_sync_delta_from": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "heat_cf_sync_finish": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]),
     "heat_cf_get_device_view": (C.c_int, [C.c_void_p, C.POINTER(DeviceView)]),
     "heat_cf_copy_to_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
     "heat_cf_epoch": (C.c_uint64, [C.c_void_p]),
@@ -272,6 +275,21 @@ class Engine:
         (device pointers; asynchronous on the engine's stream)."""
         _check(load().heat_cf_sync_apply(self._h, C.c_void_p(ref_ptr), C.c_void_p(sum_ptr),
                                          C.c_void_p(mine_ptr) if mine_ptr else None, scale))
+
+    def sync_apply_snap(self, x_ptr, snap_ptr):
+        """W_item += x (x_ptr 0: nothing to add); snap = W_item — the one pass of the pipelined exchange that runs on the
+        engine's stream (device pointers)."""
+        _check(load().heat_cf_sync_apply_snap(self._h, C.c_void_p(x_ptr) if x_ptr else None, C.c_void_p(snap_ptr)))
+
+    def sync_delta_from(self, snap_ptr, ref_ptr, mine_ptr, sum_ptr, stream):
+        """mine = sum = snap - ref on `stream` (a hipStream_t handle of the caller)."""
+        _check(load().heat_cf_sync_delta_from(self._h, C.c_void_p(snap_ptr), C.c_void_p(ref_ptr), C.c_void_p(mine_ptr) if mine_ptr else None,
+                                              C.c_void_p(sum_ptr), C.c_void_p(stream) if stream else None))
+
+    def sync_finish(self, ref_ptr, sum_ptr, mine_x_ptr, scale, stream):
+        """s = scale * sum; x = s - mine (over mine); ref += s on `stream`."""
+        _check(load().heat_cf_sync_finish(self._h, C.c_void_p(ref_ptr), C.c_void_p(sum_ptr), C.c_void_p(mine_x_ptr), scale,
+                                          C.c_void_p(stream) if stream else None))
 
     def zero_grad(self):
         _check(load().heat_cf_zero_grad(self._h))

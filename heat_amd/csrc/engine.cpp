@@ -1082,6 +1082,35 @@ int heat_cf_sync_apply(heat_cf_engine* e, void* d_ref, const void* d_sum, const 
     return HEAT_CF_OK;
 }
 
+int heat_cf_sync_apply_snap(heat_cf_engine* e, const void* d_x, void* d_snap)
+{
+    if (!e || !d_snap) return fail(HEAT_CF_EINVAL, "engine / buffer is NULL");
+    if (((uintptr_t)d_x | (uintptr_t)d_snap) & 15u) return fail(HEAT_CF_EINVAL, "buffers must be 16-byte aligned");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(launch_item_apply_snap(e->d_item_w, (const float*)d_x, (float*)d_snap, (size_t)e->cfg.num_items * e->cfg.emb_dim, e->stream));
+    return HEAT_CF_OK;
+}
+
+int heat_cf_sync_delta_from(heat_cf_engine* e, const void* d_snap, const void* d_ref, void* d_mine, void* d_sum, void* stream)
+{
+    if (!e || !d_snap || !d_ref || !d_sum) return fail(HEAT_CF_EINVAL, "engine / buffer is NULL");
+    if (((uintptr_t)d_snap | (uintptr_t)d_ref | (uintptr_t)d_mine | (uintptr_t)d_sum) & 15u) return fail(HEAT_CF_EINVAL, "buffers must be 16-byte aligned");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(launch_item_delta((const float*)d_snap, (const float*)d_ref, (float*)d_mine, (float*)d_sum,
+                              (size_t)e->cfg.num_items * e->cfg.emb_dim, (hipStream_t)stream));
+    return HEAT_CF_OK;
+}
+
+int heat_cf_sync_finish(heat_cf_engine* e, void* d_ref, const void* d_sum, void* d_mine_x, float scale, void* stream)
+{
+    if (!e || !d_ref || !d_sum || !d_mine_x) return fail(HEAT_CF_EINVAL, "engine / buffer is NULL");
+    if (((uintptr_t)d_ref | (uintptr_t)d_mine_x | (uintptr_t)d_sum) & 15u) return fail(HEAT_CF_EINVAL, "buffers must be 16-byte aligned");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(launch_item_finish((float*)d_ref, (const float*)d_sum, (float*)d_mine_x, scale,
+                               (size_t)e->cfg.num_items * e->cfg.emb_dim, (hipStream_t)stream));
+    return HEAT_CF_OK;
+}
+
 int heat_cf_synchronize(heat_cf_engine* e)
 {
     if (!e) return fail(HEAT_CF_EINVAL, "engine is NULL");

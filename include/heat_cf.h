@@ -213,6 +213,16 @@ int heat_cf_sync_from_host(heat_cf_engine* e);
  *           d_mine == NULL (nothing trained since `delta`): W_item = ref = ref + scale * sum, bit-identical on every rank */
 int heat_cf_sync_delta(heat_cf_engine* e, const void* d_ref, void* d_mine, void* d_sum);
 int heat_cf_sync_apply(heat_cf_engine* e, void* d_ref, const void* d_sum, const void* d_mine, float scale);
+/* The same exchange with ONE pass on the engine's stream (pipelined form; tables bit-identical to delta / apply with d_mine):
+ *   apply_snap (engine's stream)  : W_item += x (d_x == NULL: nothing to add) ; snap = W_item
+ *   delta_from (caller's stream)  : mine = sum = snap - ref
+ *   [caller all-reduces `sum` on that stream while the engine trains its next window]
+ *   finish     (caller's stream)  : s = scale * sum ; x = s - mine, written over d_mine_x ; ref += s
+ * `stream` is a hipStream_t of the caller (the exchange stream); the caller orders it after apply_snap and orders the next
+ * apply_snap after finish (events).  None of the three touches the persistent gradient rows. */
+int heat_cf_sync_apply_snap(heat_cf_engine* e, const void* d_x, void* d_snap);
+int heat_cf_sync_delta_from(heat_cf_engine* e, const void* d_snap, const void* d_ref, void* d_mine, void* d_sum, void* stream);
+int heat_cf_sync_finish(heat_cf_engine* e, void* d_ref, const void* d_sum, void* d_mine_x, float scale, void* stream);
 /* blocks until everything queued on the engine's stream has finished */
 int heat_cf_synchronize(heat_cf_engine* e);
 

@@ -48,6 +48,34 @@ def main():
     assert not np.array_equal(i0, iw)
     np.testing.assert_allclose(i1, i0, rtol=0, atol=2e-5)     # (W - ref) + ref costs 1 ulp per sync
     np.testing.assert_allclose(u1, u0, rtol=0, atol=2e-5)
+    # the overlapped exchange in its two forms — delta + apply on the training stream, or only `W += x; snap = W` there and
+    # the rest on an exchange stream (pipelined) — with the all-reduce, the direct exchange and a drained pipeline at the
+    # end: the same algebra, so bit-identical tables
+    outs = {}
+    for pipelined in (False, True):
+        for collective in ("all_reduce", "direct"):
+            side = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(side):
+                t_clicks = torch.from_numpy(clicks.view(np.int64)).to(dev)
+                t_uw, t_iw = torch.from_numpy(uw).to(dev), torch.from_numpy(iw).to(dev)
+                eng = abi.Engine.from_device(t_clicks.data_ptr(), T, t_uw.data_ptr(), t_iw.data_ptr(), num_users=U,
+                                             num_items=I, emb_dim=d, num_negs=N, stream=side.cuda_stream, seed=3,
+                                             flags=abi.FLAG_SERIAL | abi.FLAG_SAMPLING_CALL, keep=(t_clicks, t_uw, t_iw))
+                tr = ItemSync(eng, t_iw, 1, sync_interactions=400, mode="sum", force_collective=True, overlap=True,
+                              defer_final=True, pipelined=pipelined, collective=collective)
+                assert tr.pipelined == pipelined and tr.describe()["pipelined"] == pipelined
+                for _ in range(3):
+                    tr.train_one_epoch()
+                tr.finalize()
+                side.synchronize()
+                torch.cuda.synchronize()
+                outs[(pipelined, collective)] = (t_uw.cpu().numpy(), t_iw.cpu().numpy(), tr.exchanges)
+                eng.close()
+    base = outs[(False, "all_reduce")]
+    assert not np.array_equal(base[1], iw)
+    for key, (u, i, n_ex) in outs.items():
+        assert np.array_equal(u, base[0]) and np.array_equal(i, base[1]), key
+        assert n_ex == base[2]
     print("SYNC_OK", flush=True)
     dist.destroy_process_group()
 
