@@ -72,6 +72,10 @@ def run(cfg):
     top = topk_cpu(uw, iw, g)
     ms = ["Recall(k=20)", "NDCG(k=20)"]
     r = metrics.evaluate_topk(types.SimpleNamespace(user_items_dic=test_dic), top, ms, quiet=True, by_user_id=True)
+    if args.json:
+        return dict(shape=args.shape, scale=args.scale, aggregator=bool(args.agg), workers=S, layout="slices" if layout == 0 else "sweep",
+                    w0_batch=mb, seed=args.seed, epochs=args.epochs, clip=args.clip, lr=args.lr,
+                    losses=[float(x) for x in losses], recall20=float(r[ms[0]]), ndcg20=float(r[ms[1]]))
     return (f"streams={S} layout={'slices' if layout == 0 else 'sweep'} w0_batch={mb} losses={[round(x, 4) for x in losses]} "
             f"Recall@20={r[ms[0]]:.5f} NDCG@20={r[ms[1]]:.5f} ({dt:.0f}s)")
 
@@ -89,9 +93,22 @@ if __name__ == "__main__":
     ap.add_argument("--chunk", type=int, default=512)
     ap.add_argument("--configs", default="1:0,8:0,80:0,438:0,8:1,438:1", help="streams:layout[:w0_batch], negative streams = oracle OpenMP threads")
     ap.add_argument("--procs", type=int, default=6)
+    ap.add_argument("--json", default="", help="write the results as a JSON list (the committed fixture tests/golden/accl_stream_model.json)")
+    ap.add_argument("--seeds", default="", help="comma-separated: every config once per seed (overrides --seed)")
     a = ap.parse_args()
     build()
-    cfgs = [(a, int(c.split(":")[0]), int(c.split(":")[1]), int((c.split(":") + ["32"])[2])) for c in a.configs.split(",")]
+    import copy
+    import json
+    cfgs = []
+    for seed in ([int(x) for x in a.seeds.split(",")] if a.seeds else [a.seed]):
+        b = copy.copy(a)
+        b.seed = seed
+        cfgs += [(b, int(c.split(":")[0]), int(c.split(":")[1]), int((c.split(":") + ["32"])[2])) for c in a.configs.split(",")]
+    out = []
     with ProcessPoolExecutor(a.procs) as ex:
         for line in ex.map(run, cfgs):
             print(line, flush=True)
+            out.append(line)
+    if a.json:
+        with open(a.json, "w") as f:
+            json.dump(out, f, indent=1)
