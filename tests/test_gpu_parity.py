@@ -957,34 +957,80 @@ def test_windows_compose_to_the_whole_range():
 
 def test_randomized_serial_parity_sweep():
     """40 random configurations (emb_dim multiple of 4 up to 256, 1..100 negatives, every update policy, both samplers'
-    id ranges, ragged lengths): the serial GPU walk vs the oracle on caller-fed negatives, duplicates and negative ==
-    positive collisions included.  Catches variant-specific indexing errors (masked lanes / slots, multi-wave
-    workgroups, atomics vs stores)."""
+    id ranges, ragged lengths; every third one with behaviour aggregation: random histories of 1..119 items, W0 updates
+    every 32 calls): the serial GPU walk vs the oracle on caller-fed negatives, duplicates and negative == positive
+    collisions included.  Catches variant-specific indexing errors (masked lanes / slots, multi-wave workgroups, atomics vs
+    stores, the history gather and the d x d product).
+    Aggregation cases carry a second arbiter: the compounding user blend drives the user rows to small norms, where two
+    fp32 implementations separate quickly (tools/serial_sweep.py 400 11: 3 of 133 such cases end 1.3x - 9x beyond the table
+    tolerance; profiles/r03_serial_arbiter.txt).  Such a case passes when the GPU is at least as close to the float64
+    trajectory (tests/f64_model.py) as the fp32 oracle is — the oracle's own distance from it is then what the two differ by."""
+    from tests import serial_cases
     rng = np.random.default_rng(2024)
     modes = [abi.UPDATE_OVERWRITE, abi.UPDATE_ATOMIC_W, abi.UPDATE_ATOMIC_WG, abi.UPDATE_ATOMIC_POS, abi.UPDATE_AUTO,
              16 + 0x1C, 16 + 0x10]   # raw bits: late re-read of negative rows (positives atomic / nothing atomic)
+    seen_agg = 0
     for case in range(40):
         d = int(rng.choice([4, 8, 12, 20, 32, 48, 64, 96, 128, 160, 256]))
         N = int(rng.choice([1, 2, 3, 5, 8, 16, 17, 31, 32, 50, 64, 100]))
         U = int(rng.integers(2, 12))
         I = int(rng.integers(max(3, N // 4), 400))
         T = int(rng.integers(1, 150))
-        mode = modes[case % len(modes)]
+        agg = case % 3 == 2
+        mode = modes[case % len(modes)] if not agg else abi.UPDATE_AUTO
         clicks = np.stack([np.sort(rng.integers(0, U, T)), rng.integers(0, I, T)], axis=1).astype(np.uint64)
         uw = (rng.standard_normal((U, d)) * 0.1).astype(np.float32)
         iw = (rng.standard_normal((I, d)) * 0.1).astype(np.float32)
         negs = rng.integers(0, I, size=(T, N)).astype(np.uint64)
-        ug, ig, uo, io = uw.copy(), iw.copy(), uw.copy(), iw.copy()
-        eng = abi.Engine(clicks, ug, ig, num_negs=N, flags=abi.FLAG_SERIAL, update_mode=mode, clip_val=0.5, l_r=0.01)
-        lg = eng.train_range(0, T, negs)
-        eng.sync_to_host()
-        name = eng.kernel_name
-        eng.close()
-        lo = orc.Engine(clicks, uo, io, num_negs=N, clip_val=0.5, l_r=0.01).train_range(0, T, negs)
-        ctx = f"case {case}: d={d} N={N} U={U} I={I} T={T} mode={mode} {name}"
+        c = dict(d=d, N=N, U=U, I=I, T=T, agg=agg, mode=mode, clicks=clicks, uw=uw, iw=iw, negs=negs, his=None, masks=None, w0=None)
+        if agg:
+            H = int(rng.integers(1, 120))
+            c["masks"] = rng.integers(1, H + 1, size=(U, 1)).astype(np.uint64)
+            c["his"] = rng.integers(0, I, size=(U, H)).astype(np.uint64)
+            c["w0"] = (rng.standard_normal((d, d)) * 0.05).astype(np.float32)
+            seen_agg += 1
+        ug, ig, w0g, name = serial_cases.run_gpu(c, want_loss=True)
+        lg = serial_cases.run_gpu.last_loss
+        uo, io, w0o = serial_cases.run_oracle(c, want_loss=True)
+        lo = serial_cases.run_oracle.last_loss
+        ctx = f"case {case}: d={d} N={N} U={U} I={I} T={T} mode={mode} agg={agg} {name}"
+        e_go = serial_cases.dist((ug, ig, w0g), (uo, io, w0o))
+        if agg and e_go > 1.0:
+            f = serial_cases.run_f64(c)
+            e_gf, e_of = serial_cases.dist((ug, ig, w0g), f), serial_cases.dist((uo, io, w0o), f)
+            print(ctx, f"gpu-oracle {e_go:.3g} gpu-f64 {e_gf:.3g} oracle-f64 {e_of:.3g} (tolerance units)")
+            assert e_gf <= max(1.0, e_of), ctx
+            continue
         assert abs(lg - lo) <= 2e-5 * max(1.0, abs(lo)), ctx
-        assert np.abs(ug - uo).max() <= 3e-4 * np.abs(uo).max(), ctx
-        assert np.abs(ig - io).max() <= 3e-4 * np.abs(io).max(), ctx
+        assert e_go <= 1.0, ctx       # tables (and W0) within 3e-4 of their largest entry
+    assert seen_agg == 13
+
+
+def test_serial_aggregation_outliers_are_conditioning():
+    """The three aggregation cases of `tools/serial_sweep.py 400 11` that end beyond the suite's table tolerance (cases 68, 344,
+    362: emb_dim 8 / 20 / 20, 5-lane or 2-lane rows with masked columns, 89-92 dependent steps on 3-6 users), regenerated
+    from the sweep's own generator and arbitrated: the serial GPU walk, the fp32 oracle and the float64 model on the same
+    inputs.  Measured (profiles/r03_serial_arbiter.txt, tolerance units): GPU-float64 3.8 / 0.15 / 1.8 against
+    oracle-float64 9.2 / 1.16 / 7.3 — in every case it is the fp32 ORACLE that drifts from the exact trajectory, the GPU
+    (fused multiply-adds) stays closer to it; after the first 8 steps all three agree to 1e-3 of the tolerance or better,
+    with no jump at the 32-call W0 update.  So: conditioning of the compounding blend, not the <8,*> aggregation path."""
+    from tests import serial_cases
+    want = {68: "<8,4,16,1>", 344: "<8,8,16,1>", 362: "<8,4,16,1>"}
+    for case, c in serial_cases.sweep_cases(363, 11):
+        if case not in want:
+            continue
+        g = serial_cases.run_gpu(c)
+        assert want[case] in g[3] and c["agg"], g[3]
+        o, f = serial_cases.run_oracle(c), serial_cases.run_f64(c)
+        e_go, e_gf, e_of = serial_cases.dist(g[:3], o), serial_cases.dist(g[:3], f), serial_cases.dist(o, f)
+        print(f"case {case} {g[3]}: gpu-oracle {e_go:.3g} gpu-f64 {e_gf:.3g} oracle-f64 {e_of:.3g} (units of the 3e-4 table tolerance)")
+        assert e_go > 1.0                                   # the case is an outlier of the sweep ...
+        assert e_gf <= e_of                                 # ... in which the GPU is the one closer to the exact trajectory
+        assert e_go <= e_gf + e_of + 1e-6                   # (triangle inequality: nothing else separates them)
+        # short horizon: no indexing error shows in the first steps, including the first W0 update at call 32
+        for steps in (1, 8, 33):
+            gs, os_, fs = serial_cases.run_gpu(c, steps), serial_cases.run_oracle(c, steps), serial_cases.run_f64(c, steps)
+            assert serial_cases.dist(gs[:3], fs) <= max(0.25, 1.5 * serial_cases.dist(os_, fs)), (case, steps)
 
 
 @pytest.mark.parametrize("accl,nproc", [(False, 1), (True, 1), (False, 2), (True, 2)])

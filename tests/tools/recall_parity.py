@@ -28,6 +28,8 @@ ap.add_argument("--lr", type=float, default=0.01)
 ap.add_argument("--zipf", type=float, default=1.0, help="item popularity exponent of the synthetic graph")
 ap.add_argument("--interactions", type=int, default=0, help="override the shape's number of train interactions")
 ap.add_argument("--in-cluster", type=float, default=0.8)
+ap.add_argument("--users", type=int, default=0, help="with --interactions: override the shape's number of users")
+ap.add_argument("--items", type=int, default=0, help="with --interactions: override the shape's number of items")
 ap.add_argument("--oracle-seeds", type=str, default="", help="seeds the oracle runs for (default: every seed)")
 ap.add_argument("--agg", action="store_true", help="behaviour aggregation (ACCL) on both sides")
 ap.add_argument("--tile", action="store_true", help="random-tile negative sampler (neg_sampler 1, tile 512, refresh 8192; the "
@@ -36,6 +38,7 @@ args = ap.parse_args()
 
 if args.interactions:
     _U, _I, _T, d, N = synthetic.SHAPES[args.shape]
+    _U, _I = args.users or _U, args.items or _I
     g = synthetic.make_graph(_U, _I, args.interactions, seed=2022, n_clusters=args.clusters, zipf_s=args.zipf, in_cluster=args.in_cluster)
 else:
     g, d, N = synthetic.make_named(args.shape, scale=args.scale, n_clusters=args.clusters, zipf_s=args.zipf, in_cluster=args.in_cluster)

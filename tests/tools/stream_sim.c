@@ -8,7 +8,9 @@
  *   layout 1: chunks of `chunk` interactions dealt round-robin, chunk c to stream c % S: all streams sweep the list
  *             together, the idealised `#pragma omp for schedule(dynamic, chunk)` of train/engine.cpp:327
  * mb: calls a worker accumulates before it applies its W0 step (32 = behavior_aggregators.cpp:36,141-146).
- * Negatives: a counter-based generator keyed by (seed, epoch, interaction index, slot), i.e. independent of S and layout.
+ * Negatives: a counter-based generator keyed by (seed, epoch, interaction index, slot), i.e. independent of S and layout; or
+ * (worker_sampler) the reference's own per-worker sampler through its sampling() call — the random-tile sampler when
+ * cfg.neg_sampler == 1, one tile per worker refreshed every refresh_interval calls of that worker.
  */
 #include "../../oracle/cf_oracle.h"
 #include <stdlib.h>
@@ -22,14 +24,17 @@ static inline uint64_t mix64(uint64_t x)
     return x ^ (x >> 31);
 }
 
-double sim_epoch(orc_engine* e, int S, int layout, uint64_t chunk, uint64_t seed, int mb)
+double sim_epoch(orc_engine* e, int S, int layout, uint64_t chunk, uint64_t seed, int mb, int worker_sampler)
 {
     const uint64_t n = e->data_rows, N = e->cfg.num_negs, I = e->cfg.num_items;
     orc_worker** w = (orc_worker**)calloc((size_t)S, sizeof(orc_worker*));
     uint64_t* neg = (uint64_t*)calloc(N, sizeof(uint64_t));
+    orc_sampler* samp = (orc_sampler*)calloc((size_t)S, sizeof(orc_sampler));
     for (int s = 0; s < S; ++s)
     {
         w[s] = orc_worker_create(e);
+        /* train/engine.cpp:302-311: one sampler per worker, seeded (epoch + 1) * worker id; the tile sampler when cfg.neg_sampler == 1 */
+        if (worker_sampler) orc_sampler_init(&samp[s], &e->cfg, (e->epoch + 1) * (uint64_t)s, e->cfg.neg_sampler == 1);
         if (mb > 0 && mb != 32)
         {
             /* the same W0 step per call, lr/32 * (means (x) f_grad), applied every `mb` calls of the worker instead of every 32 */
@@ -44,7 +49,8 @@ double sim_epoch(orc_engine* e, int S, int layout, uint64_t chunk, uint64_t seed
     do                                                                                          \
     {                                                                                           \
         const uint64_t u_ = e->clicks[2 * (i)], p_ = e->clicks[2 * (i) + 1];                    \
-        for (uint64_t k = 0; k < N; ++k)                                                        \
+        if (worker_sampler) orc_sampler_sampling(&samp[s], neg); /* train/engine.cpp:333 */     \
+        else for (uint64_t k = 0; k < N; ++k)                                                   \
         {                                                                                       \
             uint64_t id = (uint64_t)(((unsigned __int128)mix64(key ^ mix64((i) * 131ull + k)) * I) >> 64); \
             if (id == p_) id = (id + 1) % I;                                                    \
@@ -76,6 +82,8 @@ double sim_epoch(orc_engine* e, int S, int layout, uint64_t chunk, uint64_t seed
     }
 #undef STEP
     for (int s = 0; s < S; ++s) orc_worker_destroy(w[s]);
+    if (worker_sampler) for (int s = 0; s < S; ++s) orc_sampler_free(&samp[s]);
+    free(samp);
     free(w);
     free(neg);
     orc_engine_zero_grad(e);

@@ -51,18 +51,20 @@ def run(cfg):
         his, masks = synthetic.make_history(g, 100, seed=2022)
         w0 = (np.random.default_rng(args.seed).standard_normal((d, d)) * 0.01).astype(np.float32)
         kw = dict(his=his, masks=masks, w0=w0, use_aggregator=True)
+    if args.tile:
+        kw.update(neg_sampler=1, tile_size=512, refresh_interval=8192)
     e = orc.Engine(g.clicks, uw, iw, num_negs=N, clip_val=args.clip, l_r=args.lr, **kw)
     lib = C.CDLL(SO)
     lib.sim_epoch.restype = C.c_double
-    lib.sim_epoch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_int]
+    lib.sim_epoch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_int, C.c_int]
     t0 = time.time()
     losses = []
     for _ in range(args.epochs):
         if S < 0:   # the oracle's own OpenMP epoch with -S threads
             os.environ["OMP_NUM_THREADS"] = str(-S)
-            losses.append(e.train_one_epoch(num_threads=-S))
+            losses.append(e.train_one_epoch(num_threads=-S, sampler_call=int(args.tile)))
         else:
-            losses.append(lib.sim_epoch(C.cast(e._e, C.c_void_p), S, layout, args.chunk, args.seed, mb))
+            losses.append(lib.sim_epoch(C.cast(e._e, C.c_void_p), S, layout, args.chunk, args.seed, mb, int(args.tile)))
     dt = time.time() - t0
     test_dic = {}
     ep = g.test_indptr.astype(np.int64)
@@ -73,7 +75,7 @@ def run(cfg):
     ms = ["Recall(k=20)", "NDCG(k=20)"]
     r = metrics.evaluate_topk(types.SimpleNamespace(user_items_dic=test_dic), top, ms, quiet=True, by_user_id=True)
     if args.json:
-        return dict(shape=args.shape, scale=args.scale, aggregator=bool(args.agg), workers=S, layout="slices" if layout == 0 else "sweep",
+        return dict(shape=args.shape, scale=args.scale, aggregator=bool(args.agg), tile_sampler=bool(args.tile), workers=S, layout="slices" if layout == 0 else "sweep",
                     w0_batch=mb, seed=args.seed, epochs=args.epochs, clip=args.clip, lr=args.lr,
                     losses=[float(x) for x in losses], recall20=float(r[ms[0]]), ndcg20=float(r[ms[1]]))
     return (f"streams={S} layout={'slices' if layout == 0 else 'sweep'} w0_batch={mb} losses={[round(x, 4) for x in losses]} "
@@ -87,6 +89,7 @@ if __name__ == "__main__":
     ap.add_argument("--clusters", type=int, default=0)
     ap.add_argument("--epochs", type=int, default=5)
     ap.add_argument("--agg", action="store_true")
+    ap.add_argument("--tile", action="store_true", help="random-tile sampler (tile 512, refresh 8192), one per worker, sampling() call")
     ap.add_argument("--clip", type=float, default=1.0)
     ap.add_argument("--lr", type=float, default=0.01)
     ap.add_argument("--seed", type=int, default=2022)
