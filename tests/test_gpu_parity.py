@@ -542,6 +542,89 @@ def test_recall_ndcg_parity_gowalla_config():
     assert abs(gpu[:, 2].mean() - ora[:, 2].mean()) <= 0.03 * ora[:, 2].mean(), (gpu, ora)
 
 
+def test_accl_hogwild_parity_amazonbooks_shape():
+    """Behaviour aggregation (ACCL) in Hogwild mode at AmazonBooks shape, yaml hyper-parameters, 5 epochs, the
+    engine's default plan (438 four-wave streams), three seeds per side.
+
+    Two references, because ACCL's loss curve depends on the NUMBER OF WORKERS even without any asynchrony
+    (profiles/r03_accl_worker_count.txt): the 8-thread OpenMP oracle, and the oracle's own forward_backward driven as S
+    lockstep workers, sequentially consistent (tests/tools/stream_sim.c; committed fixture tests/golden/accl_stream_model.json,
+    S = 8 and S = 438).  The chain that is asserted:
+      * model(8 workers)   vs the 8-thread oracle : Recall@20 +-1e-3, final loss within 3.5 % — the lockstep model IS the oracle;
+      * GPU (438 streams)  vs model(438 workers)  : Recall@20 +-1e-3, final loss within 3.5 % — at a matched worker count the
+        Hogwild GPU run adds nothing to what the reference's algorithm does with that many workers;
+      * GPU vs the 8-thread oracle: Recall@20 within -1e-3 ... +2e-3 (the model's own 8 -> 438 shift is +1.1e-3: more workers
+        rank slightly BETTER), final loss +10 ... +20 % (the model's shift: +13 %; one shared W0 pushed by S users at once).
+    NDCG@20 of this mode scatters by +-4e-3 between runs of either side on the popularity-only graph (the top ranks are the
+    hottest items, whose rows move until the last step), so it is held to 3e-3 on the means."""
+    import json
+    import os
+    import types
+    from concurrent.futures import ThreadPoolExecutor
+    from heat_amd.cf import metrics
+    seeds = (2022, 7, 99)
+    g, d, N = synthetic.make_named("amazonbooks")
+    his, masks = synthetic.make_history(g, 100, seed=2022)
+    ep = g.test_indptr.astype(np.int64)
+    test = types.SimpleNamespace(user_items_dic={u: g.test_items[ep[u]:ep[u + 1]].tolist()
+                                                 for u in range(g.num_users) if ep[u + 1] > ep[u]})
+    ms = ["Recall(k=20)", "NDCG(k=20)"]
+
+    def rank_and_score(uw, iw):
+        ev = abi.Engine(g.clicks[:1].copy(), uw, iw, num_negs=N)
+        top = ev.topk(20, mask_indptr=g.train_indptr, mask_items=g.train_items)
+        ev.close()
+        r = metrics.evaluate_topk(test, top, ms, quiet=True, by_user_id=True)
+        return r[ms[0]], r[ms[1]]
+
+    def tables(seed):
+        uw, iw = synthetic.init_embeddings(g.num_users, g.num_items, d, seed=seed)
+        w0 = (np.random.default_rng(seed).standard_normal((d, d)) * 0.01).astype(np.float32)
+        return uw, iw, w0
+
+    def oracle_run(seed):
+        uo, io, w0 = tables(seed)
+        ora = orc.Engine(g.clicks, uo, io, num_negs=N, his=his, masks=masks, w0=w0, use_aggregator=True)
+        return uo, io, [ora.train_one_epoch(num_threads=8) for _ in range(5)]
+
+    with ThreadPoolExecutor(max_workers=2) as pool:
+        futures = [pool.submit(oracle_run, s) for s in seeds]
+        gpu, name = [], None
+        for seed in seeds:
+            uw, iw, w0 = tables(seed)
+            eng = abi.Engine(g.clicks, uw, iw, num_negs=N, seed=seed, his=his, masks=masks, w0=w0, use_aggregator=True,
+                             flags=abi.FLAG_LAZY_SYNC)
+            losses = [eng.train_one_epoch() for _ in range(5)]
+            eng.sync_to_host()
+            name = eng.kernel_name
+            eng.close()
+            gpu.append(rank_and_score(uw, iw) + tuple(losses))
+        ora = []
+        for f in futures:
+            uo, io, losses = f.result()
+            ora.append(rank_and_score(uo, io) + tuple(losses))
+    gpu, ora = np.array(gpu), np.array(ora)
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "accl_stream_model.json")) as f:
+        fixture = json.load(f)
+    model = {w: np.array([[r["recall20"], r["ndcg20"]] + r["losses"] for r in fixture if r["workers"] == w and r["seed"] in seeds])
+             for w in (8, 438)}
+    assert model[8].shape == model[438].shape == gpu.shape == ora.shape == (3, 7)
+    print(f"{name}\n gpu (Recall, NDCG, 5 epoch losses) per seed:\n{gpu}\n 8-thread oracle:\n{ora}\n model 8 workers:\n{model[8]}\n model 438:\n{model[438]}")
+    assert "streams=438" in name and "<16,1,16,4>" in name, name
+    g_, o_, m8, m438 = gpu.mean(axis=0), ora.mean(axis=0), model[8].mean(axis=0), model[438].mean(axis=0)
+    # the lockstep model at the oracle's worker count is the oracle
+    assert abs(m8[0] - o_[0]) <= 1e-3 and abs(m8[6] - o_[6]) <= 0.035 * o_[6], (m8, o_)
+    # the GPU at its worker count is the model at that worker count
+    assert abs(g_[0] - m438[0]) <= 1e-3, (g_, m438)
+    assert abs(g_[6] - m438[6]) <= 0.035 * m438[6], (g_, m438)
+    assert np.all(np.abs(g_[3:] - m438[3:]) <= 0.06 * m438[3:]), (g_, m438)          # every later epoch of the curve, loosely
+    assert abs(g_[1] - m438[1]) <= 3e-3, (g_, m438)
+    # against the 8-thread oracle: the worker-count shift, no more
+    assert -1e-3 <= g_[0] - o_[0] <= 2e-3, (g_, o_)
+    assert abs(g_[1] - o_[1]) <= 3e-3, (g_, o_)
+    assert 1.08 * o_[6] <= g_[6] <= 1.22 * o_[6], (g_, o_)
+
+
 def test_recall_ndcg_parity_amazonbooks_clustered():
     """The headline config (AmazonBooks yaml: d=64, 16 negatives, clip_val 1.0, 5 epochs) on the clustered variant of the
     AmazonBooks-shaped graph — the more discriminating twin of test_recall_ndcg_parity_amazonbooks_shape."""
