@@ -380,6 +380,7 @@ TrainArgs make_args(const heat_cf_engine* e, uint64_t begin, uint64_t end)
     a.refresh_interval = (uint32_t)std::max<uint64_t>(1, e->cfg.refresh_interval);
     a.upd_bits = (uint32_t)e->upd;
     a.align_cap = (e->upd & 0xF) == 0 ? 4096u : 0u; // overwrite mode keeps a user's run inside one stream; atomic modes need not
+    if (const char* ac = std::getenv("HEAT_CF_ALIGN_CAP")) a.align_cap = (uint32_t)std::strtoul(ac, nullptr, 10);   // experiments
     a.lr = e->lr;
     a.clip = e->cfg.clip_val;
     a.key = epoch_key(e->cfg.seed, e->epoch);
@@ -906,7 +907,7 @@ static int topk_fused(heat_cf_engine* e, uint64_t u_begin, uint64_t u_end, uint3
     if (const char* pc = getenv("HEAT_CF_TOPK_PANEL")) // tests: walk several user panels with a small table
         panel_cap = std::max<uint64_t>(1, strtoull(pc, nullptr, 10));
     const uint64_t panel = std::min<uint64_t>(nu, panel_cap);
-    const uint32_t slots = 2 * e->cu_count; // 2 workgroups (<= 256 VGPRs, <= 80 KB LDS each) per CU
+    const uint32_t slots = e->cu_count;     // topk_fused_splits knows how many workgroups of its kernel a compute unit holds
     const uint64_t last = nu % panel ? nu % panel : panel;
     const size_t part_elems = (size_t)k * std::max<uint64_t>(panel * topk_fused_splits((uint32_t)panel, (uint32_t)I, slots),
                                                              last * topk_fused_splits((uint32_t)last, (uint32_t)I, slots));

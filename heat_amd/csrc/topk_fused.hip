@@ -17,6 +17,9 @@
 #include "eval_kernels.hpp"
 
 #include <math.h>
+#include <type_traits>
+#include <cstdlib>
+#include <cstring>
 
 namespace heatcf
 {
@@ -406,6 +409,363 @@ template <int CAP> __global__ __launch_bounds__(256, 2) void topk_fused_kernel(F
     }
 }
 
+// ---- round 3: 128 users x 128 items per workgroup, every user owned by ONE wave ------------------------------------------
+// What the 64 x 128 kernel above spends beyond its arithmetic (profiles/r02_topk_sq_counters.txt: matrix pipe busy 3.9 of
+// 11.9 ms at AmazonBooks shape) is per-tile fixed cost: seven workgroup barriers, both operands restaged through LDS, and a
+// candidate path in which four waves push into each other's queues, meet at a barrier and insert one candidate per LDS
+// round trip.  This form removes the sharing instead of tuning it:
+//   * wave w owns users [32 w, 32 w + 32) of the tile and ALL 128 items: four 32 x 32 accumulators (one wave per SIMD
+//     reaches the f32 matrix rate with four independent accumulators, MI355X_MICROARCH.md 'Matrix cores');
+//   * the A operand (the wave's 32 user rows) never changes over the item loop: it lives in REGISTERS for the whole kernel
+//     (lane (n, h): U[32 w + n][2 kp + h], kp = 0 .. d/2) — no staging, no LDS reads, no barrier for it;
+//   * only the item slab goes through LDS (64 k-values x 128 items = 33.8 KB), double-buffered where it fits: ONE barrier
+//     per slab, the next slab's global loads in flight under the MFMAs;
+//   * selection is wave-local: a score that passes its user's threshold is APPENDED to that user's buffer (LDS atomic slot
+//     counter, all lanes in parallel); only a full buffer is merged into the sorted list, by rank counting over the wave
+//     (one ballot per buffered element), and only then the threshold rises.  No queue, no barrier, no cross-wave traffic.
+//     A stale threshold admits more candidates than the exact one would ((k + B) ln(n / (k + B)) instead of k ln(n / k) per
+//     user) — they cost one parallel append each instead of one serial insertion.
+// Scores, order and ids are those of the kernel above (same fmaf chain per score, same (score desc, id asc) comparator).
+constexpr int TU2 = 128;   // users per workgroup
+constexpr int KS2 = 64;    // k-values per item slab
+constexpr int LDB2 = TI + 4;
+
+template <int CAP, int BUF, bool DBUF> struct __attribute__((aligned(16))) Shared2T
+{
+    float    b[DBUF ? 2 : 1][KS2 / 2][LDB2][2];   // [k pair][item][k parity]
+    float    topv[TU2][CAP];                      // per user: the best so far, best first (entries >= k are scratch)
+    uint32_t topi[TU2][CAP];
+    float    bufv[TU2][BUF];                      // per user: appended, not yet merged
+    uint32_t bufi[TU2][BUF];
+    uint32_t cnt[TU2];
+    float    thr_v[TU2];                          // entry k - 1 at the last merge: what a candidate has to beat
+    float    thr_sh[TU2];                         // best k-th score any item split of these users has published
+    uint32_t thr_i[TU2];
+    uint32_t mbits[TU2][4];                       // train items of the current tile
+};
+
+// Merge user u's buffer (n entries) into its sorted list; the whole wave works on one user.  CAP = 32: lanes 0..31 hold the
+// list, lanes 32..63 the buffer; CAP = 64: every lane holds a list entry and lanes 0..31 a buffer entry as well.
+// The rank of a buffered element x among all elements is one ballot over "my element ranks ahead of x"; a list element
+// moves down by the number of buffered elements ahead of it.
+template <int CAP, int BUF, class Shared> __device__ __forceinline__ void merge_user(Shared& s, uint32_t u, uint32_t k, int lane)
+{
+    static_assert(BUF <= 32 && (CAP == 32 || CAP == 64), "layout of merge_user");
+    const uint32_t n = min(s.cnt[u], (uint32_t)BUF);
+    const bool listl = lane < CAP;
+    const int bl = CAP == 32 ? lane - 32 : lane;                          // buffer slot this lane holds
+    const bool bufl = bl >= 0 && (uint32_t)bl < n;
+    const float    lv = listl ? s.topv[u][lane] : -INFINITY;
+    const uint32_t li = listl ? s.topi[u][lane] : NONE;
+    const float    bv = bufl ? s.bufv[u][bl] : -INFINITY;
+    const uint32_t bi = bufl ? s.bufi[u][bl] : NONE;
+    uint32_t shift = 0u, myrank = 0u;
+    for (uint32_t j = 0; j < n; ++j)
+    {
+        const int src = CAP == 32 ? (int)j + 32 : (int)j;
+        const float    xv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bv), src));
+        const uint32_t xi = (uint32_t)__builtin_amdgcn_readlane((int)bi, src);
+        const bool l_ahead = listl && ahead(lv, li, xv, xi);
+        const bool b_ahead = bufl && (ahead(bv, bi, xv, xi));
+        const uint32_t r = (uint32_t)__popcll(__ballot(l_ahead)) + (uint32_t)__popcll(__ballot(b_ahead));
+        shift += (listl && !l_ahead) ? 1u : 0u;                           // x ranks ahead of my list element (no two elements are equal)
+        if (bl == (int)j) myrank = r;
+    }
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t nl = (uint32_t)lane + shift;
+    if (listl && nl < (uint32_t)CAP)
+    {
+        s.topv[u][nl] = lv;
+        s.topi[u][nl] = li;
+        if (nl == k - 1) { s.thr_v[u] = lv; s.thr_i[u] = li; }
+    }
+    if (bufl && myrank < (uint32_t)CAP)
+    {
+        s.topv[u][myrank] = bv;
+        s.topi[u][myrank] = bi;
+        if (myrank == k - 1) { s.thr_v[u] = bv; s.thr_i[u] = bi; }
+    }
+    if (lane == 0) s.cnt[u] = 0u;
+    __builtin_amdgcn_wave_barrier();
+    __asm__ volatile("" ::: "memory");
+}
+
+// merge every user of this wave whose buffer holds at least `at` entries
+template <int CAP, int BUF, class Shared> __device__ __forceinline__ void merge_ready(Shared& s, int wave, uint32_t k, uint32_t at, int lane)
+{
+    uint64_t m = __ballot(lane < 32 && s.cnt[wave * 32 + (lane & 31)] >= at);
+    while (m != 0ull)
+    {
+        const int ul = __builtin_ctzll(m);
+        m &= m - 1ull;
+        merge_user<CAP, BUF>(s, (uint32_t)(wave * 32 + ul), k, lane);
+    }
+}
+
+struct Slab2Regs { f4 v[8]; };   // thread (sr, sc): item rows sr and 64 + sr, columns sc*4 + 16 j (j < 4) of the slab
+
+__device__ __forceinline__ void load_slab2(const FusedArgs& p, uint32_t i0, uint32_t k0, int sr, int sc, Slab2Regs& g)
+{
+    const uint32_t d = p.d, last = p.num_items - 1u;
+    const float* v0 = p.V + (size_t)min(i0 + (uint32_t)sr, last) * d;
+    const float* v1 = p.V + (size_t)min(i0 + 64u + (uint32_t)sr, last) * d;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+    {
+        const uint32_t kk = min(k0 + (uint32_t)(sc * 4 + 16 * j), d - 4u);   // columns past emb_dim: clamped, never multiplied
+        g.v[j] = *(const f4*)(v0 + kk);
+        g.v[4 + j] = *(const f4*)(v1 + kk);
+    }
+}
+
+template <class Shared> __device__ __forceinline__ void store_slab2(Shared& s, int buf, int sr, int sc, const Slab2Regs& g)
+{
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+    {
+        const int kp = (sc * 4 + 16 * j) / 2;
+        *(f2*)&s.b[buf][kp][sr][0] = f2{g.v[j][0], g.v[j][1]};
+        *(f2*)&s.b[buf][kp + 1][sr][0] = f2{g.v[j][2], g.v[j][3]};
+        *(f2*)&s.b[buf][kp][64 + sr][0] = f2{g.v[4 + j][0], g.v[4 + j][1]};
+        *(f2*)&s.b[buf][kp + 1][64 + sr][0] = f2{g.v[4 + j][2], g.v[4 + j][3]};
+    }
+}
+
+// AREG = A registers per lane = k pairs the kernel can hold (emb_dim <= 2 * AREG)
+template <int CAP, int BUF, bool DBUF, int AREG> __global__ __launch_bounds__(256, 1) void topk_fused2_kernel(FusedArgs p)
+{
+    typedef Shared2T<CAP, BUF, DBUF> Shared;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem2[];
+    Shared& s = *reinterpret_cast<Shared*>(smem2);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 31, h = lane >> 5;
+    const uint32_t u0 = blockIdx.x * (uint32_t)TU2;
+    const uint32_t ub = u0 + (uint32_t)(wave * 32);            // first user of this wave
+    const uint32_t ntiles = (p.num_items + TI - 1) / TI;
+    const uint32_t t_begin = blockIdx.y * p.tiles_per_split;
+    const uint32_t t_end = min(ntiles, t_begin + p.tiles_per_split);
+    const uint32_t d = p.d, k = p.k;
+    const uint32_t kpairs = d / 2;                              // emb_dim % 4 == 0
+    const uint32_t nslab = (d + KS2 - 1) / KS2;
+
+    // A operand: lane (n, h) keeps U[ub + n][2 kp + h] for every k pair
+    float a[AREG];
+    {
+        const float* ur = p.U + (size_t)min(ub + (uint32_t)n, p.rows - 1u) * d;
+#pragma unroll
+        for (int kp = 0; kp < AREG; ++kp) a[kp] = (uint32_t)kp < kpairs ? ur[2 * kp + h] : 0.0f;
+    }
+    uint32_t ulive = 0u;       // bit r: the user of result register r exists
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+        if (ub + (uint32_t)(8 * (r >> 2) + 4 * h + (r & 3)) < p.rows) ulive |= 1u << r;
+
+    for (int t = tid; t < TU2 * CAP; t += 256)
+    {
+        (&s.topv[0][0])[t] = -INFINITY;
+        (&s.topi[0][0])[t] = NONE;
+    }
+    if (tid < TU2)
+    {
+        s.cnt[tid] = 0u;
+        s.thr_v[tid] = -INFINITY;
+        s.thr_sh[tid] = (p.thr_shared && u0 + tid < p.rows) ? __builtin_nontemporal_load(p.thr_shared + u0 + tid) : -INFINITY;
+        s.thr_i[tid] = NONE;
+    }
+
+    // lane ul < 32 of every wave walks the sorted train items of its user: cur / nxt / nx2 = cursor, its item, the one after
+    uint64_t cur = 0, hi = 0;
+    uint32_t nxt = NONE, nx2 = NONE;
+    if (lane < 32 && p.indptr && ub + lane < p.rows)
+    {
+        uint64_t lo = p.indptr[ub + lane];
+        hi = p.indptr[ub + lane + 1];
+        const uint32_t first = t_begin * (uint32_t)TI;
+        uint64_t x = lo, y = hi;
+        while (x < y)
+        {
+            const uint64_t m = (x + y) >> 1;
+            if (p.items[m] < first) x = m + 1;
+            else y = m;
+        }
+        cur = x;
+        nxt = cur < hi ? p.items[cur] : NONE;
+        nx2 = cur + 1 < hi ? p.items[cur + 1] : NONE;
+    }
+
+    const int sr = tid >> 2, sc = tid & 3;
+    Slab2Regs regs;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) regs.v[j] = f4{0, 0, 0, 0};
+    // slabs are numbered through the whole item range of this workgroup: g = (tile - t_begin) * nslab + slab
+    const uint32_t gtotal = t_begin < t_end ? (t_end - t_begin) * nslab : 0u;
+    auto slab_tile = [&](uint32_t g) { return t_begin + g / nslab; };
+    auto slab_k0 = [&](uint32_t g) { return (g % nslab) * (uint32_t)KS2; };
+    if (gtotal > 0)
+    {
+        load_slab2(p, slab_tile(0) * (uint32_t)TI, slab_k0(0), sr, sc, regs);
+        if (DBUF)
+        {
+            store_slab2(s, 0, sr, sc, regs);
+            if (gtotal > 1) load_slab2(p, slab_tile(1) * (uint32_t)TI, slab_k0(1), sr, sc, regs);
+        }
+    }
+    __syncthreads();
+
+    uint32_t g = 0;
+    for (uint32_t tile = t_begin; tile < t_end; ++tile)
+    {
+        const uint32_t i0 = tile * (uint32_t)TI;
+        if (lane < 32)
+        {
+            const uint32_t u = (uint32_t)(wave * 32 + lane);
+            s.mbits[u][0] = 0; s.mbits[u][1] = 0; s.mbits[u][2] = 0; s.mbits[u][3] = 0;
+            const uint32_t tile_end = i0 + TI;
+            while (nxt < tile_end)
+            {
+                const uint32_t bit = nxt - i0;
+                s.mbits[u][bit >> 5] |= 1u << (bit & 31);
+                ++cur;
+                nxt = nx2;
+                nx2 = cur + 1 < hi ? p.items[cur + 1] : NONE;
+            }
+        }
+
+        f16v acc[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[c][r] = 0.0f;
+
+        for (uint32_t sl = 0; sl < nslab; ++sl, ++g)
+        {
+            int cb = 0;
+            if (DBUF)
+            {
+                cb = (int)(g & 1u);
+                // the other buffer was last read in iteration g - 1, which every wave left through the barrier below
+                if (g + 1 < gtotal)
+                {
+                    store_slab2(s, cb ^ 1, sr, sc, regs);
+                    if (g + 2 < gtotal) load_slab2(p, slab_tile(g + 2) * (uint32_t)TI, slab_k0(g + 2), sr, sc, regs);
+                }
+            }
+            else
+            {
+                store_slab2(s, 0, sr, sc, regs);
+                __syncthreads();
+                if (g + 1 < gtotal) load_slab2(p, slab_tile(g + 1) * (uint32_t)TI, slab_k0(g + 1), sr, sc, regs);
+            }
+            const uint32_t kbase = sl * (uint32_t)(KS2 / 2);                 // first k pair of this slab
+            // a[] is indexed statically: `sl` selects among the AREG / 32 slabs a kernel variant can see (wave-uniform)
+            auto slab_mfma = [&](auto full_tag) __attribute__((always_inline))
+            {
+#pragma unroll
+                for (int kp = 0; kp < KS2 / 2; ++kp)
+                {
+                    float av = 0.0f;
+#pragma unroll
+                    for (int q = 0; q < AREG / (KS2 / 2); ++q)
+                        if (sl == (uint32_t)q) av = a[q * (KS2 / 2) + kp];
+                    if (decltype(full_tag)::value || kbase + (uint32_t)kp < kpairs)
+                    {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c)
+                            acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, s.b[cb][kp][32 * c + n][h], acc[c], 0, 0, 0);
+                    }
+                }
+            };
+            if (kbase + (uint32_t)(KS2 / 2) <= kpairs) slab_mfma(std::true_type{});
+            else slab_mfma(std::false_type{});
+            __syncthreads();
+        }
+
+        // ---- selection, wave-local: lane's results acc[c][r] = user ub + 8 (r / 4) + 4 h + (r % 4), item i0 + 32 c + n
+        uint32_t cand[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+        {
+            const f4 tl = *(const f4*)&s.thr_v[wave * 32 + 8 * q + 4 * h];
+            const f4 ts = *(const f4*)&s.thr_sh[wave * 32 + 8 * q + 4 * h];
+            const f4 t4 = f4{fmaxf(tl[0], ts[0]), fmaxf(tl[1], ts[1]), fmaxf(tl[2], ts[2]), fmaxf(tl[3], ts[3])};
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+            {
+                const int r = 4 * q + j;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) cand[c] |= (!(acc[c][r] < t4[j]) ? 1u : 0u) << r;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+        {
+            const uint32_t item = i0 + (uint32_t)(32 * c + n);
+            uint32_t todo = item < p.num_items ? (cand[c] & ulive) : 0u;
+            while (__ballot(todo != 0u) != 0ull)
+            {
+                bool full = false;
+                if (todo != 0u)
+                {
+                    const int r = __builtin_ctz(todo);
+                    const uint32_t u = (uint32_t)(wave * 32 + 8 * (r >> 2) + 4 * h + (r & 3));
+                    float v = 0.0f;
+#pragma unroll
+                    for (int r2 = 0; r2 < 16; ++r2)
+                        if (r2 == r) v = acc[c][r2];
+                    if ((s.mbits[u][c] >> n) & 1u) v = -INFINITY;             // a train item scores -inf (metrics.py:24)
+                    const float tv = s.thr_v[u];
+                    const bool pass = v == v && !(v < s.thr_sh[u]) && ahead(v, item, tv, s.thr_i[u]);
+                    bool done = true;
+                    if (pass)
+                    {
+                        const uint32_t slot = atomicAdd(&s.cnt[u], 1u);
+                        if (slot < (uint32_t)BUF)
+                        {
+                            s.bufv[u][slot] = v;
+                            s.bufi[u][slot] = item;
+                        }
+                        else
+                        {
+                            done = false;                                     // buffer full: merge, then try again
+                            full = true;
+                        }
+                    }
+                    if (done) todo &= todo - 1u;
+                }
+                if (__ballot(full) != 0ull) merge_ready<CAP, BUF>(s, wave, k, (uint32_t)BUF, lane);
+            }
+        }
+        // a buffer that is nearly full is merged now, between tiles, so that the threshold does not lag a whole buffer behind
+        merge_ready<CAP, BUF>(s, wave, k, (uint32_t)(BUF * 3 / 4), lane);
+
+        // threshold exchange between the item splits of these users (see the 64 x 128 kernel)
+        if (p.thr_shared && lane < 32 && ub + lane < p.rows)
+        {
+            const uint32_t u = (uint32_t)(wave * 32 + lane);
+            const float mine = s.thr_v[u];
+            float* gthr = p.thr_shared + ub + lane;
+            if (mine > s.thr_sh[u])
+            {
+                if (mine >= 0.0f) atomicMax(reinterpret_cast<int*>(gthr), __float_as_int(mine));
+                else atomicMin(reinterpret_cast<unsigned int*>(gthr), __float_as_uint(mine));
+            }
+            s.thr_sh[u] = fmaxf(mine, __builtin_nontemporal_load(gthr));
+        }
+        __builtin_amdgcn_wave_barrier();
+        __asm__ volatile("" ::: "memory");
+    }
+    merge_ready<CAP, BUF>(s, wave, k, 1u, lane);
+    __syncthreads();
+    for (int t = tid; t < TU2 * (int)k; t += 256)
+    {
+        const uint32_t u = (uint32_t)t / k, j = (uint32_t)t % k;
+        if (u0 + u >= p.rows) continue;
+        const size_t o = ((size_t)blockIdx.y * p.rows + (u0 + u)) * k + j;
+        p.part_v[o] = s.topv[u][j];
+        p.part_i[o] = s.topi[u][j];
+    }
+}
+
 // One wave per user: rank the splits*k partial entries, emit the first k ids.
 __global__ __launch_bounds__(64) void topk_merge_kernel(const float* part_v, const uint32_t* part_i, uint32_t rows,
                                                         uint32_t k, uint32_t splits, uint32_t* topk)
@@ -439,16 +799,45 @@ __global__ __launch_bounds__(64) void topk_merge_kernel(const float* part_v, con
 }
 } // namespace
 
-uint32_t topk_fused_splits(uint32_t rows, uint32_t num_items, uint32_t slots)
+// which kernel runs: the 128 x 128 one (round 3) unless HEAT_CF_TOPK_KERNEL=v1 asks for the 64 x 128 one (A/B runs)
+static bool use_v2()
 {
-    const uint32_t nblocks = (rows + TU - 1) / TU, ntiles = (num_items + TI - 1) / TI;
-    if (nblocks == 0 || ntiles == 0) return 1;
-    uint32_t z = (3 * slots + nblocks - 1) / nblocks; // at least three rounds of workgroups over the chip
-    z = z < 1 ? 1 : z;
-    z = z > (uint32_t)TOPK_FUSED_MAX_SPLITS ? (uint32_t)TOPK_FUSED_MAX_SPLITS : z;
-    z = z > ntiles ? ntiles : z;
-    const uint32_t per = (ntiles + z - 1) / z;
-    return (ntiles + per - 1) / per;
+    const char* e = std::getenv("HEAT_CF_TOPK_KERNEL");
+    return !(e && std::strcmp(e, "v1") == 0);
+}
+
+// Item-range splits per user block for a chip with `cus` compute units.  Workgroups are dispatched as slots free up, so a
+// launch costs about ceil(workgroups / slots) rounds of one split's tiles: the split count that minimises rounds x tiles
+// per split wins (a fractional last round is a tail in which most of the chip idles), with 1 % per split for the
+// warm-up candidates and the partial lists every extra split adds.
+uint32_t topk_fused_splits(uint32_t rows, uint32_t num_items, uint32_t cus)
+{
+    const bool v2 = use_v2();
+    const uint32_t tu = v2 ? (uint32_t)TU2 : (uint32_t)TU, slots = v2 ? cus : 2u * cus;
+    const uint32_t nblocks = (rows + tu - 1) / tu, ntiles = (num_items + TI - 1) / TI;
+    if (nblocks == 0 || ntiles == 0 || slots == 0) return 1;
+    uint32_t best = 1;
+    double best_cost = 0.0;
+    for (uint32_t z = 1; z <= (uint32_t)TOPK_FUSED_MAX_SPLITS && z <= ntiles; ++z)
+    {
+        const uint32_t per = (ntiles + z - 1) / z, ze = (ntiles + per - 1) / per;     // no empty split
+        if (ze != z) continue;
+        const uint64_t wgs = (uint64_t)nblocks * ze, rounds = (wgs + slots - 1) / slots;
+        const double cost = (double)rounds * (double)per * (1.0 + 0.01 * (double)ze);
+        if (best_cost == 0.0 || cost < best_cost) { best_cost = cost; best = ze; }
+    }
+    return best;
+}
+
+template <int CAP, int BUF, bool DBUF, int AREG>
+static hipError_t launch_v2(const FusedArgs& p, uint32_t splits, hipStream_t s)
+{
+    auto kern = topk_fused2_kernel<CAP, BUF, DBUF, AREG>;
+    const size_t lds = sizeof(Shared2T<CAP, BUF, DBUF>);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3((p.rows + TU2 - 1) / TU2, splits), dim3(256), lds, s, p);
+    return hipGetLastError();
 }
 
 hipError_t launch_topk_fused(const float* user_rows, const float* item_w, uint32_t rows, uint32_t num_items,
@@ -470,9 +859,23 @@ hipError_t launch_topk_fused(const float* user_rows, const float* item_w, uint32
         hipError_t e0 = hipMemsetD32Async((hipDeviceptr_t)thr_shared, (int)0xFF800000u, rows, s);   // -inf
         if (e0 != hipSuccess) return e0;
     }
-    if (k <= 32) hipLaunchKernelGGL(topk_fused_kernel<32>, dim3((rows + TU - 1) / TU, splits), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL(topk_fused_kernel<64>, dim3((rows + TU - 1) / TU, splits), dim3(256), 0, s, p);
-    hipError_t err = hipGetLastError();
+    hipError_t err;
+    if (use_v2() && emb_dim <= 256)
+    {
+        // list slots 32 / 64 by k; A registers 32 / 64 / 128 by emb_dim; the item slab is double-buffered where LDS allows
+        if (k <= 32)
+            err = emb_dim <= 64 ? launch_v2<32, 32, true, 32>(p, splits, s)
+                : emb_dim <= 128 ? launch_v2<32, 32, true, 64>(p, splits, s) : launch_v2<32, 32, true, 128>(p, splits, s);
+        else
+            err = emb_dim <= 64 ? launch_v2<64, 32, false, 32>(p, splits, s)
+                : emb_dim <= 128 ? launch_v2<64, 32, false, 64>(p, splits, s) : launch_v2<64, 32, false, 128>(p, splits, s);
+    }
+    else
+    {
+        if (k <= 32) hipLaunchKernelGGL(topk_fused_kernel<32>, dim3((rows + TU - 1) / TU, splits), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL(topk_fused_kernel<64>, dim3((rows + TU - 1) / TU, splits), dim3(256), 0, s, p);
+        err = hipGetLastError();
+    }
     if (err != hipSuccess) return err;
     hipLaunchKernelGGL(topk_merge_kernel, dim3(rows), dim3(64), 0, s, part_v, part_i, rows, k, splits, topk);
     return hipGetLastError();

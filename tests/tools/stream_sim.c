@@ -34,7 +34,9 @@ double sim_epoch(orc_engine* e, int S, int layout, uint64_t chunk, uint64_t seed
     {
         w[s] = orc_worker_create(e);
         /* train/engine.cpp:302-311: one sampler per worker, seeded (epoch + 1) * worker id; the tile sampler when cfg.neg_sampler == 1 */
-        if (worker_sampler) orc_sampler_init(&samp[s], &e->cfg, (e->epoch + 1) * (uint64_t)s, e->cfg.neg_sampler == 1);
+        if (worker_sampler)
+            orc_sampler_init(&samp[s], &e->cfg, worker_sampler == 2 ? mix64(seed * 7919ull + e->epoch * 1000003ull + (uint64_t)s) /* no seed shared by two (epoch, worker) pairs */
+                                                                    : (e->epoch + 1) * (uint64_t)s, e->cfg.neg_sampler == 1);
         if (mb > 0 && mb != 32)
         {
             /* the same W0 step per call, lr/32 * (means (x) f_grad), applied every `mb` calls of the worker instead of every 32 */

@@ -44,7 +44,11 @@ def topk_cpu(uw, iw, g, k=20, block=1024):
 def run(cfg):
     args, S, layout, mb = cfg
     os.environ["OMP_NUM_THREADS"] = "1"
-    g, d, N = synthetic.make_named(args.shape, scale=args.scale, n_clusters=args.clusters)
+    if args.interactions:
+        _U, _I, _T, d, N = synthetic.SHAPES[args.shape]
+        g = synthetic.make_graph(args.users or _U, args.items or _I, args.interactions, seed=2022, n_clusters=args.clusters)
+    else:
+        g, d, N = synthetic.make_named(args.shape, scale=args.scale, n_clusters=args.clusters)
     uw, iw = synthetic.init_embeddings(g.num_users, g.num_items, d, seed=args.seed)
     kw = {}
     if args.agg:
@@ -64,7 +68,7 @@ def run(cfg):
             os.environ["OMP_NUM_THREADS"] = str(-S)
             losses.append(e.train_one_epoch(num_threads=-S, sampler_call=int(args.tile)))
         else:
-            losses.append(lib.sim_epoch(C.cast(e._e, C.c_void_p), S, layout, args.chunk, args.seed, mb, int(args.tile)))
+            losses.append(lib.sim_epoch(C.cast(e._e, C.c_void_p), S, layout, args.chunk, args.seed, mb, (2 if args.unique_sampler_seeds else 1) if args.tile else 0))
     dt = time.time() - t0
     test_dic = {}
     ep = g.test_indptr.astype(np.int64)
@@ -88,7 +92,12 @@ if __name__ == "__main__":
     ap.add_argument("--scale", type=float, default=1.0)
     ap.add_argument("--clusters", type=int, default=0)
     ap.add_argument("--epochs", type=int, default=5)
+    ap.add_argument("--users", type=int, default=0)
+    ap.add_argument("--items", type=int, default=0)
+    ap.add_argument("--interactions", type=int, default=0, help="with --users / --items: a graph of another size with the shape's emb_dim / num_negs")
     ap.add_argument("--agg", action="store_true")
+    ap.add_argument("--unique-sampler-seeds", action="store_true", help="with --tile: every (epoch, worker) its own sampler seed instead of "
+                    "the reference's (epoch + 1) * worker id (train/engine.cpp:302), which repeats seeds across epochs and workers")
     ap.add_argument("--tile", action="store_true", help="random-tile sampler (tile 512, refresh 8192), one per worker, sampling() call")
     ap.add_argument("--clip", type=float, default=1.0)
     ap.add_argument("--lr", type=float, default=0.01)
