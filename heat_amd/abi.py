@@ -64,6 +64,7 @@ SYMBOLS = {
     "heat_cf_synchronize": (C.c_int, [C.c_void_p]),
     "heat_cf_sync_delta": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "heat_cf_sync_apply": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float]),
+    "heat_cf_sync_apply_delta": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float]),
     "heat_cf_sync_apply_snap": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "heat_cf_sync_delta_from": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "heat_cf_sync_finish": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]),
@@ -275,6 +276,11 @@ class Engine:
         (device pointers; asynchronous on the engine's stream)."""
         _check(load().heat_cf_sync_apply(self._h, C.c_void_p(ref_ptr), C.c_void_p(sum_ptr),
                                          C.c_void_p(mine_ptr) if mine_ptr else None, scale))
+
+    def sync_apply_delta(self, ref_ptr, sum_ptr, mine_ptr, scale=1.0):
+        """W_item += scale * sum - mine; ref += scale * sum; mine = sum = W_item - ref — apply of one exchange and delta of
+        the next in one pass (device pointers; asynchronous on the engine's stream)."""
+        _check(load().heat_cf_sync_apply_delta(self._h, C.c_void_p(ref_ptr), C.c_void_p(sum_ptr), C.c_void_p(mine_ptr), scale))
 
     def sync_apply_snap(self, x_ptr, snap_ptr):
         """W_item += x (x_ptr 0: nothing to add); snap = W_item — the one pass of the pipelined exchange that runs on the

@@ -213,12 +213,25 @@ class ItemSync:
         """Start an exchange of everything this rank changed since the reference."""
         if self.pipelined and not blocking:
             return self._post_pipelined()
-        self._complete()                        # the reference must be current before the next delta
+        with_mine = not blocking
+        fused = False
+        if (with_mine and self.native and self.pending is not None and self.pending[1] and not self._x_ready
+                and hasattr(self.engine, "sync_apply_delta")):
+            # steady state of the overlapped schedule: the apply of the exchange in flight and the delta of this one in ONE
+            # pass over the tables (heat_cf_sync_apply_delta: same expressions, same bits, one launch and 47 MB less)
+            work = self.pending[0]
+            if work is not None:
+                work.wait()
+            self.pending = None
+            self.engine.sync_apply_delta(self.ref.data_ptr(), self.sum.data_ptr(), self.mine.data_ptr(), self.scale)
+            fused = True
+        else:
+            self._complete()                    # the reference must be current before the next delta
         for t in self.mean_tensors:
             self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
             t.div_(self.world)
-        with_mine = not blocking
-        self._delta(with_mine)
+        if not fused:
+            self._delta(with_mine)
         work = self._exchange(blocking)
         self.pending = (work if not blocking else None, with_mine)
         self.exchanges += 1

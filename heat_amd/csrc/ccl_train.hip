@@ -859,6 +859,18 @@ __global__ __launch_bounds__(64 * NW * TS) void ccl_train_kernel(TrainArgs a)
                 if ((g % GPF) == GPF - 1) __builtin_amdgcn_sched_barrier(0);    // bound how far G fetches are hoisted
             }
             };
+            if constexpr (!RR && NW == 1 && GPF >= NGW)
+            {
+                // Every G row of the interaction is already in flight (GPF == NGW) and the rows arrive together.  Waiting
+                // for all of them HERE, where only loads are outstanding, is free — and it spares the sweep its in-loop
+                // waits: the compiler cannot count stores behind the wave-uniform duplicate branch, so it guarded the last
+                // group's G row with `s_waitcnt vmcnt(0)` AFTER the stores of the groups before it, i.e. one full
+                // write-through store drain per interaction (round 3, read off the ISA of <16,4,16,1>).
+                // simm16: vmcnt = 0 (bits 3:0 and 15:14), expcnt = 7 and lgkmcnt = 15 (no wait)
+                __builtin_amdgcn_sched_barrier(0);   // the softmax arithmetic above stays above: it is the shadow the G rows arrive in
+                __builtin_amdgcn_s_waitcnt(0x0F70);
+                __builtin_amdgcn_sched_barrier(0);
+            }
             if constexpr (RR || TS > 1) sweep(std::integral_constant<int, 0>{});    // bits 0-1 are rejected with bit 4 (engine.cpp)
             else if constexpr (NW > 1 || NGW > 16) sweep(std::integral_constant<int, 2>{});
             else if (!neg_w_atomic && !neg_g_atomic) sweep(std::integral_constant<int, 0>{});

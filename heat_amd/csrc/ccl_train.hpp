@@ -75,6 +75,7 @@ hipError_t launch_pack_history(const uint64_t* his, const uint64_t* masks, uint3
 // item_sync.hip
 hipError_t launch_item_delta(const float* w, const float* ref, float* mine, float* sum, size_t n_floats, hipStream_t s);
 hipError_t launch_item_apply(float* w, float* ref, const float* sum, const float* mine, float scale, size_t n_floats, hipStream_t s);
+hipError_t launch_item_apply_delta(float* w, float* ref, float* sum, float* mine, float scale, size_t n_floats, hipStream_t s);
 hipError_t launch_item_apply_snap(float* w, const float* x, float* snap, size_t n_floats, hipStream_t s);
 hipError_t launch_item_finish(float* ref, const float* sum, float* mine_x, float scale, size_t n_floats, hipStream_t s);
 hipError_t launch_sample_negs(const TrainArgs& a, uint32_t grid, uint64_t out_base, uint64_t* out, hipStream_t s);

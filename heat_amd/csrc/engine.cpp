@@ -1083,6 +1083,16 @@ int heat_cf_sync_apply(heat_cf_engine* e, void* d_ref, const void* d_sum, const 
     return HEAT_CF_OK;
 }
 
+int heat_cf_sync_apply_delta(heat_cf_engine* e, void* d_ref, void* d_sum, void* d_mine, float scale)
+{
+    if (!e || !d_ref || !d_sum || !d_mine) return fail(HEAT_CF_EINVAL, "engine / buffer is NULL");
+    if (((uintptr_t)d_ref | (uintptr_t)d_mine | (uintptr_t)d_sum) & 15u) return fail(HEAT_CF_EINVAL, "buffers must be 16-byte aligned");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(launch_item_apply_delta(e->d_item_w, (float*)d_ref, (float*)d_sum, (float*)d_mine, scale,
+                                    (size_t)e->cfg.num_items * e->cfg.emb_dim, e->stream));
+    return HEAT_CF_OK;
+}
+
 int heat_cf_sync_apply_snap(heat_cf_engine* e, const void* d_x, void* d_snap)
 {
     if (!e || !d_snap) return fail(HEAT_CF_EINVAL, "engine / buffer is NULL");

@@ -420,86 +420,51 @@ template <int CAP> __global__ __launch_bounds__(256, 2) void topk_fused_kernel(F
 //     (lane (n, h): U[32 w + n][2 kp + h], kp = 0 .. d/2) — no staging, no LDS reads, no barrier for it;
 //   * only the item slab goes through LDS (64 k-values x 128 items = 33.8 KB), double-buffered where it fits: ONE barrier
 //     per slab, the next slab's global loads in flight under the MFMAs;
-//   * selection is wave-local: a score that passes its user's threshold is APPENDED to that user's buffer (LDS atomic slot
-//     counter, all lanes in parallel); only a full buffer is merged into the sorted list, by rank counting over the wave
-//     (one ballot per buffered element), and only then the threshold rises.  No queue, no barrier, no cross-wave traffic.
-//     A stale threshold admits more candidates than the exact one would ((k + B) ln(n / (k + B)) instead of k ln(n / k) per
-//     user) — they cost one parallel append each instead of one serial insertion.
+//   * selection is wave-local: a score that passes its user's threshold goes into the WAVE'S OWN queue (LDS atomic slot
+//     counter, all lanes in parallel) and the wave then inserts its queue into its users' sorted lists, one ballot +
+//     popcount insertion per candidate against the always-current threshold.  No workgroup barrier, no cross-wave traffic.
+//     (First form of this round: per-user append buffers merged by rank counting when full — the stale thresholds tripled
+//     the candidates and a 32-entry merge cost ~5000 cycles of ballot / popcount round trips: 14.5 ms against 11.9.)
 // Scores, order and ids are those of the kernel above (same fmaf chain per score, same (score desc, id asc) comparator).
 constexpr int TU2 = 128;   // users per workgroup
 constexpr int KS2 = 64;    // k-values per item slab
 constexpr int LDB2 = TI + 4;
 
-template <int CAP, int BUF, bool DBUF> struct __attribute__((aligned(16))) Shared2T
+constexpr int QW2 = 256;   // candidate queue entries per wave
+
+template <int CAP, bool DBUF> struct __attribute__((aligned(16))) Shared2T
 {
     float    b[DBUF ? 2 : 1][KS2 / 2][LDB2][2];   // [k pair][item][k parity]
-    float    topv[TU2][CAP];                      // per user: the best so far, best first (entries >= k are scratch)
+    float    topv[TU2][CAP];                      // per user: the k best so far, best first
     uint32_t topi[TU2][CAP];
-    float    bufv[TU2][BUF];                      // per user: appended, not yet merged
-    uint32_t bufi[TU2][BUF];
-    uint32_t cnt[TU2];
-    float    thr_v[TU2];                          // entry k - 1 at the last merge: what a candidate has to beat
+    float    thr_v[TU2];                          // = entry k - 1, the one a candidate has to beat
     float    thr_sh[TU2];                         // best k-th score any item split of these users has published
     uint32_t thr_i[TU2];
     uint32_t mbits[TU2][4];                       // train items of the current tile
+    float    qv[4][QW2];                          // per wave: candidates of the current tile, in arrival order
+    uint32_t qi[4][QW2];
+    uint8_t  qu[4][QW2];
+    uint32_t qn[4];
 };
 
-// Merge user u's buffer (n entries) into its sorted list; the whole wave works on one user.  CAP = 32: lanes 0..31 hold the
-// list, lanes 32..63 the buffer; CAP = 64: every lane holds a list entry and lanes 0..31 a buffer entry as well.
-// The rank of a buffered element x among all elements is one ballot over "my element ranks ahead of x"; a list element
-// moves down by the number of buffered elements ahead of it.
-template <int CAP, int BUF, class Shared> __device__ __forceinline__ void merge_user(Shared& s, uint32_t u, uint32_t k, int lane)
+// every wave empties ITS queue into the lists of ITS users: no other wave ever touches either
+template <class Shared> __device__ __forceinline__ void drain2(Shared& s, uint32_t k, int wave, int lane)
 {
-    static_assert(BUF <= 32 && (CAP == 32 || CAP == 64), "layout of merge_user");
-    const uint32_t n = min(s.cnt[u], (uint32_t)BUF);
-    const bool listl = lane < CAP;
-    const int bl = CAP == 32 ? lane - 32 : lane;                          // buffer slot this lane holds
-    const bool bufl = bl >= 0 && (uint32_t)bl < n;
-    const float    lv = listl ? s.topv[u][lane] : -INFINITY;
-    const uint32_t li = listl ? s.topi[u][lane] : NONE;
-    const float    bv = bufl ? s.bufv[u][bl] : -INFINITY;
-    const uint32_t bi = bufl ? s.bufi[u][bl] : NONE;
-    uint32_t shift = 0u, myrank = 0u;
-    for (uint32_t j = 0; j < n; ++j)
+    const uint32_t n = min(s.qn[wave], (uint32_t)QW2);
+    for (uint32_t base = 0; base < n; base += 64)
     {
-        const int src = CAP == 32 ? (int)j + 32 : (int)j;
-        const float    xv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bv), src));
-        const uint32_t xi = (uint32_t)__builtin_amdgcn_readlane((int)bi, src);
-        const bool l_ahead = listl && ahead(lv, li, xv, xi);
-        const bool b_ahead = bufl && (ahead(bv, bi, xv, xi));
-        const uint32_t r = (uint32_t)__popcll(__ballot(l_ahead)) + (uint32_t)__popcll(__ballot(b_ahead));
-        shift += (listl && !l_ahead) ? 1u : 0u;                           // x ranks ahead of my list element (no two elements are equal)
-        if (bl == (int)j) myrank = r;
+        const uint32_t e = base + (uint32_t)lane;
+        const uint32_t cu = e < n ? (uint32_t)s.qu[wave][e] : 0u;
+        const uint32_t ci = e < n ? s.qi[wave][e] : 0u;
+        const float    cv = e < n ? s.qv[wave][e] : 0.0f;
+        const int cnt = (int)min(64u, n - base);
+        for (int j = 0; j < cnt; ++j)
+            insert(s, (uint32_t)__builtin_amdgcn_readlane((int)cu, j), (uint32_t)__builtin_amdgcn_readlane((int)ci, j),
+                   __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cv), j)), k, lane);
     }
-    __builtin_amdgcn_wave_barrier();
-    const uint32_t nl = (uint32_t)lane + shift;
-    if (listl && nl < (uint32_t)CAP)
-    {
-        s.topv[u][nl] = lv;
-        s.topi[u][nl] = li;
-        if (nl == k - 1) { s.thr_v[u] = lv; s.thr_i[u] = li; }
-    }
-    if (bufl && myrank < (uint32_t)CAP)
-    {
-        s.topv[u][myrank] = bv;
-        s.topi[u][myrank] = bi;
-        if (myrank == k - 1) { s.thr_v[u] = bv; s.thr_i[u] = bi; }
-    }
-    if (lane == 0) s.cnt[u] = 0u;
+    if (lane == 0) s.qn[wave] = 0u;
     __builtin_amdgcn_wave_barrier();
     __asm__ volatile("" ::: "memory");
-}
-
-// merge every user of this wave whose buffer holds at least `at` entries
-template <int CAP, int BUF, class Shared> __device__ __forceinline__ void merge_ready(Shared& s, int wave, uint32_t k, uint32_t at, int lane)
-{
-    uint64_t m = __ballot(lane < 32 && s.cnt[wave * 32 + (lane & 31)] >= at);
-    while (m != 0ull)
-    {
-        const int ul = __builtin_ctzll(m);
-        m &= m - 1ull;
-        merge_user<CAP, BUF>(s, (uint32_t)(wave * 32 + ul), k, lane);
-    }
 }
 
 struct Slab2Regs { f4 v[8]; };   // thread (sr, sc): item rows sr and 64 + sr, columns sc*4 + 16 j (j < 4) of the slab
@@ -532,9 +497,9 @@ template <class Shared> __device__ __forceinline__ void store_slab2(Shared& s, i
 }
 
 // AREG = A registers per lane = k pairs the kernel can hold (emb_dim <= 2 * AREG)
-template <int CAP, int BUF, bool DBUF, int AREG> __global__ __launch_bounds__(256, 1) void topk_fused2_kernel(FusedArgs p)
+template <int CAP, bool DBUF, int AREG> __global__ __launch_bounds__(256, 1) void topk_fused2_kernel(FusedArgs p)
 {
-    typedef Shared2T<CAP, BUF, DBUF> Shared;
+    typedef Shared2T<CAP, DBUF> Shared;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem2[];
     Shared& s = *reinterpret_cast<Shared*>(smem2);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -565,9 +530,9 @@ template <int CAP, int BUF, bool DBUF, int AREG> __global__ __launch_bounds__(25
         (&s.topv[0][0])[t] = -INFINITY;
         (&s.topi[0][0])[t] = NONE;
     }
+    if (tid < 4) s.qn[tid] = 0u;
     if (tid < TU2)
     {
-        s.cnt[tid] = 0u;
         s.thr_v[tid] = -INFINITY;
         s.thr_sh[tid] = (p.thr_shared && u0 + tid < p.rows) ? __builtin_nontemporal_load(p.thr_shared + u0 + tid) : -INFINITY;
         s.thr_i[tid] = NONE;
@@ -713,30 +678,28 @@ template <int CAP, int BUF, bool DBUF, int AREG> __global__ __launch_bounds__(25
                     for (int r2 = 0; r2 < 16; ++r2)
                         if (r2 == r) v = acc[c][r2];
                     if ((s.mbits[u][c] >> n) & 1u) v = -INFINITY;             // a train item scores -inf (metrics.py:24)
-                    const float tv = s.thr_v[u];
-                    const bool pass = v == v && !(v < s.thr_sh[u]) && ahead(v, item, tv, s.thr_i[u]);
                     bool done = true;
-                    if (pass)
+                    if (v == v && !(v < s.thr_v[u]) && !(v < s.thr_sh[u]))
                     {
-                        const uint32_t slot = atomicAdd(&s.cnt[u], 1u);
-                        if (slot < (uint32_t)BUF)
+                        const uint32_t slot = atomicAdd(&s.qn[wave], 1u);
+                        if (slot < (uint32_t)QW2)
                         {
-                            s.bufv[u][slot] = v;
-                            s.bufi[u][slot] = item;
+                            s.qv[wave][slot] = v;
+                            s.qi[wave][slot] = item;
+                            s.qu[wave][slot] = (uint8_t)u;
                         }
                         else
                         {
-                            done = false;                                     // buffer full: merge, then try again
+                            done = false;                                     // queue full (first tiles): drain, then try again
                             full = true;
                         }
                     }
                     if (done) todo &= todo - 1u;
                 }
-                if (__ballot(full) != 0ull) merge_ready<CAP, BUF>(s, wave, k, (uint32_t)BUF, lane);
+                if (__ballot(full) != 0ull) drain2(s, k, wave, lane);         // raises the thresholds the retries are checked against
             }
         }
-        // a buffer that is nearly full is merged now, between tiles, so that the threshold does not lag a whole buffer behind
-        merge_ready<CAP, BUF>(s, wave, k, (uint32_t)(BUF * 3 / 4), lane);
+        if (s.qn[wave] != 0u) drain2(s, k, wave, lane);
 
         // threshold exchange between the item splits of these users (see the 64 x 128 kernel)
         if (p.thr_shared && lane < 32 && ub + lane < p.rows)
@@ -754,7 +717,6 @@ template <int CAP, int BUF, bool DBUF, int AREG> __global__ __launch_bounds__(25
         __builtin_amdgcn_wave_barrier();
         __asm__ volatile("" ::: "memory");
     }
-    merge_ready<CAP, BUF>(s, wave, k, 1u, lane);
     __syncthreads();
     for (int t = tid; t < TU2 * (int)k; t += 256)
     {
@@ -829,11 +791,11 @@ uint32_t topk_fused_splits(uint32_t rows, uint32_t num_items, uint32_t cus)
     return best;
 }
 
-template <int CAP, int BUF, bool DBUF, int AREG>
+template <int CAP, bool DBUF, int AREG>
 static hipError_t launch_v2(const FusedArgs& p, uint32_t splits, hipStream_t s)
 {
-    auto kern = topk_fused2_kernel<CAP, BUF, DBUF, AREG>;
-    const size_t lds = sizeof(Shared2T<CAP, BUF, DBUF>);
+    auto kern = topk_fused2_kernel<CAP, DBUF, AREG>;
+    const size_t lds = sizeof(Shared2T<CAP, DBUF>);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3((p.rows + TU2 - 1) / TU2, splits), dim3(256), lds, s, p);
@@ -864,11 +826,11 @@ hipError_t launch_topk_fused(const float* user_rows, const float* item_w, uint32
     {
         // list slots 32 / 64 by k; A registers 32 / 64 / 128 by emb_dim; the item slab is double-buffered where LDS allows
         if (k <= 32)
-            err = emb_dim <= 64 ? launch_v2<32, 32, true, 32>(p, splits, s)
-                : emb_dim <= 128 ? launch_v2<32, 32, true, 64>(p, splits, s) : launch_v2<32, 32, true, 128>(p, splits, s);
+            err = emb_dim <= 64 ? launch_v2<32, true, 32>(p, splits, s)
+                : emb_dim <= 128 ? launch_v2<32, true, 64>(p, splits, s) : launch_v2<32, true, 128>(p, splits, s);
         else
-            err = emb_dim <= 64 ? launch_v2<64, 32, false, 32>(p, splits, s)
-                : emb_dim <= 128 ? launch_v2<64, 32, false, 64>(p, splits, s) : launch_v2<64, 32, false, 128>(p, splits, s);
+            err = emb_dim <= 64 ? launch_v2<64, true, 32>(p, splits, s)
+                : emb_dim <= 128 ? launch_v2<64, true, 64>(p, splits, s) : launch_v2<64, true, 128>(p, splits, s);
     }
     else
     {

@@ -213,6 +213,9 @@ int heat_cf_sync_from_host(heat_cf_engine* e);
  *           d_mine == NULL (nothing trained since `delta`): W_item = ref = ref + scale * sum, bit-identical on every rank */
 int heat_cf_sync_delta(heat_cf_engine* e, const void* d_ref, void* d_mine, void* d_sum);
 int heat_cf_sync_apply(heat_cf_engine* e, void* d_ref, const void* d_sum, const void* d_mine, float scale);
+/* apply of one exchange and delta of the next in ONE pass (what the overlapped schedule runs at every window boundary):
+ *   W_item += scale * sum - mine ; ref += scale * sum ; mine = sum = W_item - ref      (same bits as apply, then delta) */
+int heat_cf_sync_apply_delta(heat_cf_engine* e, void* d_ref, void* d_sum, void* d_mine, float scale);
 /* The same exchange with ONE pass on the engine's stream (pipelined form; tables bit-identical to delta / apply with d_mine):
  *   apply_snap (engine's stream)  : W_item += x (d_x == NULL: nothing to add) ; snap = W_item
  *   delta_from (caller's stream)  : mine = sum = snap - ref
