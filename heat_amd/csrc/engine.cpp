@@ -137,6 +137,7 @@ struct Plan
     uint32_t cap_items = 0, cap_users = 0;
     uint32_t update_mode = 0; // resolved HEAT_CF_UPDATE_* (or the raw 16.. form)
     uint32_t upd_bits = 0;
+    const char* binding = "";  // which bound set `streams`
 };
 
 // fill = workgroups the chip can keep resident for the chosen variant (from the occupancy query; 0 = unknown: caps only)
@@ -182,15 +183,28 @@ int make_plan(const heat_cf_config* cfg, uint64_t data_rows, uint64_t fill, Plan
     const uint64_t min_slice = (wide && !cfg->use_aggregator) ? 5600 : 256;
     p->cap_users = (uint32_t)std::min<uint64_t>(0xFFFFFFFFull, std::max<uint64_t>(1, data_rows / min_slice));
     uint64_t streams = std::min<uint64_t>(p->cap_items, p->cap_users);
-    if (fill) streams = std::min(streams, fill);
+    p->binding = p->cap_items <= p->cap_users ? "in-flight touches per item row" : "interactions per stream";
+    if (fill && fill < streams)
+    {
+        streams = fill;
+        p->binding = "resident workgroups";
+    }
     // a few workgroups more than a whole number per compute unit would make those units the tail of the launch — for the
     // multi-wave workgroups, which run at what the memory system sustains; a single-wave stream between 1x and 4x the
     // CU count, and a behaviour-aggregation stream of any shape, is latency-bound and simply scales with the count
     // (aggregation at AmazonBooks shape: 256 streams 55.5 ms per epoch, 438 streams 34.9 ms)
     if (cus && p->nw > 1 && !cfg->use_aggregator && streams > cus && streams < 4ull * cus) streams -= streams % cus;
     if (streams < 1) streams = 1;
-    if (cfg->num_streams) streams = cfg->num_streams;
-    if (cfg->flags & HEAT_CF_FLAG_SERIAL) streams = 1;
+    if (cfg->num_streams)
+    {
+        streams = cfg->num_streams;
+        p->binding = "num_streams";
+    }
+    if (cfg->flags & HEAT_CF_FLAG_SERIAL)
+    {
+        streams = 1;
+        p->binding = "serial";
+    }
     p->streams = (uint32_t)streams;
     uint32_t um = cfg->update_mode;
     if (um == HEAT_CF_UPDATE_DEFAULT) um = HEAT_CF_UPDATE_AUTO;
@@ -218,7 +232,11 @@ int make_plan(const heat_cf_config* cfg, uint64_t data_rows, uint64_t fill, Plan
     // The reference's literal overwrite loses updates in proportion to the number of concurrent workers (Recall@20 0.099 vs
     // 0.209 at AmazonBooks shape with ~3000 streams, profiles/r01_recall_parity_overwrite_modes.txt): without an explicit
     // num_streams it runs at a worker count the reference itself could have (64 OpenMP threads in the paper).
-    if (bits == 0u && !cfg->num_streams && !(cfg->flags & HEAT_CF_FLAG_SERIAL) && p->streams > 64u) p->streams = 64u;
+    if (bits == 0u && !cfg->num_streams && !(cfg->flags & HEAT_CF_FLAG_SERIAL) && p->streams > 64u)
+    {
+        p->streams = 64u;
+        p->binding = "overwrite policy: a worker count the reference could have";
+    }
     p->update_mode = um;
     p->upd_bits = bits;
     return HEAT_CF_OK;
@@ -449,10 +467,10 @@ int heat_cf_plan(const heat_cf_config* cfg, uint64_t data_rows, uint64_t residen
     const int n = std::snprintf(out, (size_t)out_bytes,
                                 "{\"lanes_per_row\": %d, \"groups_per_wave\": %d, \"waves_per_workgroup\": %d, "
                                 "\"negative_capacity\": %d, \"coherence\": \"%s\", \"streams\": %u, \"cap_items\": %u, "
-                                "\"cap_users\": %u, \"update_mode\": \"%s\", \"update_bits\": %u, \"tile_in_lds\": %s}",
+                                "\"cap_users\": %u, \"binding\": \"%s\", \"update_mode\": \"%s\", \"update_bits\": %u, \"tile_in_lds\": %s}",
                                 p.lpr, p.ng, p.nw, p.ng * (64 / p.lpr) * p.nw,
                                 p.coherence == HEAT_CF_COHERENCE_DEVICE ? "device" : "plain", p.streams, p.cap_items,
-                                p.cap_users, um, p.upd_bits, tile_fits_lds(cfg, p) ? "true" : "false");
+                                p.cap_users, p.binding, um, p.upd_bits, tile_fits_lds(cfg, p) ? "true" : "false");
     if (n < 0 || (uint64_t)n >= out_bytes) return fail(HEAT_CF_EINVAL, "out buffer too small");
     return HEAT_CF_OK;
 }

@@ -160,6 +160,7 @@ struct FusedArgs
     float*          thr_shared; // [rows]: max over the item splits of a user's k-th best score so far (-inf at launch)
     float*          part_v;   // [splits, rows, k]
     uint32_t*       part_i;
+    uint32_t        ablate;   // experiments (HEAT_CF_TOPK_ABLATE): 1 = no candidate ever, 2 = candidates queued but never inserted
 };
 
 // Registers of one slab in flight: two float4 of user row u0+sr and of item rows i0+sr, i0+64+sr at columns
@@ -661,6 +662,7 @@ template <int CAP, bool DBUF, int AREG> __global__ __launch_bounds__(256, 1) voi
                 for (int c = 0; c < 4; ++c) cand[c] |= (!(acc[c][r] < t4[j]) ? 1u : 0u) << r;
             }
         }
+        if (p.ablate == 1u && acc[0][0] != 12345.678f) cand[0] = cand[1] = cand[2] = cand[3] = 0u;
 #pragma unroll
         for (int c = 0; c < 4; ++c)
         {
@@ -696,10 +698,15 @@ template <int CAP, bool DBUF, int AREG> __global__ __launch_bounds__(256, 1) voi
                     }
                     if (done) todo &= todo - 1u;
                 }
-                if (__ballot(full) != 0ull) drain2(s, k, wave, lane);         // raises the thresholds the retries are checked against
+                if (__ballot(full) != 0ull)
+                {
+                    if (p.ablate == 2u) { if (lane == 0) s.qn[wave] = 0u; __builtin_amdgcn_wave_barrier(); }
+                    else drain2(s, k, wave, lane);                            // raises the thresholds the retries are checked against
+                }
             }
         }
-        if (s.qn[wave] != 0u) drain2(s, k, wave, lane);
+        if (p.ablate == 2u) { if (lane == 0) s.qn[wave] = 0u; __builtin_amdgcn_wave_barrier(); }
+        else if (s.qn[wave] != 0u) drain2(s, k, wave, lane);
 
         // threshold exchange between the item splits of these users (see the 64 x 128 kernel)
         if (p.thr_shared && lane < 32 && ub + lane < p.rows)
@@ -816,6 +823,8 @@ hipError_t launch_topk_fused(const float* user_rows, const float* item_w, uint32
     if ((uint64_t)p.tiles_per_split * (splits - 1) >= ntiles && splits > 1) return hipErrorInvalidValue; // empty split
     p.indptr = indptr; p.items = items; p.part_v = part_v; p.part_i = part_i;
     p.thr_shared = splits > 1 ? thr_shared : nullptr;
+    p.ablate = 0u;
+    if (const char* ab = std::getenv("HEAT_CF_TOPK_ABLATE")) p.ablate = (uint32_t)std::atoi(ab);
     if (p.thr_shared)
     {
         hipError_t e0 = hipMemsetD32Async((hipDeviceptr_t)thr_shared, (int)0xFF800000u, rows, s);   // -inf

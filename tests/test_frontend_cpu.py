@@ -293,6 +293,11 @@ def test_launch_plan_host_logic():
     # a user shard of an 8-GPU job (297 591 interactions): a stream still walks >= 256 interactions
     assert abi.plan(resident_workgroups=256 * 12, **dict(A, num_users=6580, train_size=297591))["streams"] == 297591 // 256 == 1162
     assert p["streams"] == 3017 and p["update_mode"] == "ATOMIC_POS" and p["update_bits"] == 0xC and p["coherence"] == "device"
+    # the plan names the bound that set the stream count
+    assert p["binding"] == "in-flight touches per item row"
+    assert abi.plan(resident_workgroups=256 * 12, **dict(A, num_users=6580, train_size=297591))["binding"] == "interactions per stream"
+    assert abi.plan(resident_workgroups=1024, **A)["binding"] == "resident workgroups"
+    assert abi.plan(num_streams=77, **A)["binding"] == "num_streams"
     # random-tile sampler (its sampling() call): the tile's weight deltas live in LDS where tile_size x emb_dim x 4 B <= 128 KB
     T_ = dict(A, neg_sampler=1, tile_size=512, refresh_interval=8192)
     LDS = abi.FLAG_SAMPLING_CALL | abi.FLAG_TILE_LDS

