@@ -130,13 +130,20 @@ class ItemSync:
         self.mine = item_w.clone() if self.overlap else None
         self.pipelined = bool(pipelined) and self.overlap and self.native and hasattr(engine, "sync_apply_snap")
         self._x_ready = False                    # pipelined: `mine` holds x = scale * sum - mine of the previous exchange
-        if self.pipelined:
+        # An epoch of a shard of an 8-GPU job is ~1 ms: the ~50 us the host needs to issue a collective (and, pipelined, the
+        # two passes around it) would leave the training stream empty.  With a HIP engine on device tensors the host therefore
+        # only QUEUES the element-wise pass the training stream needs, records an event, and issues the rest — on the exchange
+        # stream, behind that event — after the next window's kernel has been queued (`_issue`, called from train_one_epoch).
+        self._deferred = None
+        self._defer_ok = self.overlap and self.native and getattr(item_w, "is_cuda", False) and hasattr(engine, "device_view")
+        if self._defer_ok:
             import torch
-            self.snap = item_w.clone()
             self._xs = torch.cuda.Stream(device=item_w.device)            # the exchange stream
             h = engine.device_view().stream                               # the stream the engine launches on
             self._ts = torch.cuda.ExternalStream(h, device=item_w.device) if h else torch.cuda.default_stream(item_w.device)
             self._ev_snap, self._ev_x = torch.cuda.Event(), torch.cuda.Event()
+        if self.pipelined:
+            self.snap = item_w.clone()
         self.pending = None                      # (work handle) of an all-reduce in flight
         self._n_max = None
         self.exchanges = 0
@@ -173,8 +180,15 @@ class ItemSync:
             self.ref.add_(self.sum)
             self.item_w.copy_(self.ref)
 
+    def _issue(self):
+        """Issue what a non-blocking exchange left for later (see __init__)."""
+        if self._deferred is not None:
+            fn, self._deferred = self._deferred, None
+            fn()
+
     def _complete(self):
         """Wait for the all-reduce in flight (stream-side for RCCL, host-side for gloo) and apply it."""
+        self._issue()
         if self._x_ready:                       # pipelined: the exchange stream has left x in `mine` and moved `ref`
             self._ts.wait_event(self._ev_x)
             self.engine.sync_apply_snap(self.mine.data_ptr(), self.snap.data_ptr())
@@ -193,19 +207,24 @@ class ItemSync:
         for t in self.mean_tensors:             # small replicated state (W0): where it always was, on the training stream
             self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
             t.div_(self.world)
+        self._issue()
         if self._x_ready:
             self._ts.wait_event(self._ev_x)     # long done: the previous window's collective had a whole window
         self.engine.sync_apply_snap(self.mine.data_ptr() if self._x_ready else 0, self.snap.data_ptr())
         self._ev_snap.record(self._ts)
-        with torch.cuda.stream(self._xs):
-            self._xs.wait_event(self._ev_snap)
-            self.engine.sync_delta_from(self.snap.data_ptr(), self.ref.data_ptr(), self.mine.data_ptr(), self.sum.data_ptr(),
-                                        self._xs.cuda_stream)
-            work = self._exchange(blocking=False)
-            if work is not None:
-                work.wait()                     # orders the exchange stream (RCCL) / blocks the host (gloo) behind the sum
-            self.engine.sync_finish(self.ref.data_ptr(), self.sum.data_ptr(), self.mine.data_ptr(), self.scale, self._xs.cuda_stream)
-            self._ev_x.record(self._xs)
+
+        def rest():
+            with torch.cuda.stream(self._xs):
+                self._xs.wait_event(self._ev_snap)
+                self.engine.sync_delta_from(self.snap.data_ptr(), self.ref.data_ptr(), self.mine.data_ptr(), self.sum.data_ptr(),
+                                            self._xs.cuda_stream)
+                work = self._exchange(blocking=False)
+                if work is not None:
+                    work.wait()                 # orders the exchange stream (RCCL) / blocks the host (gloo) behind the sum
+                self.engine.sync_finish(self.ref.data_ptr(), self.sum.data_ptr(), self.mine.data_ptr(), self.scale, self._xs.cuda_stream)
+                self._ev_x.record(self._xs)
+
+        self._deferred = rest                   # issued once the next window's kernel is queued
         self._x_ready = True
         self.exchanges += 1
 
@@ -215,6 +234,7 @@ class ItemSync:
             return self._post_pipelined()
         with_mine = not blocking
         fused = False
+        self._issue()
         if (with_mine and self.native and self.pending is not None and self.pending[1] and not self._x_ready
                 and hasattr(self.engine, "sync_apply_delta")):
             # steady state of the overlapped schedule: the apply of the exchange in flight and the delta of this one in ONE
@@ -232,9 +252,20 @@ class ItemSync:
             t.div_(self.world)
         if not fused:
             self._delta(with_mine)
+        self.exchanges += 1
+        if not blocking and self._defer_ok:
+            import torch
+            self._ev_snap.record(self._ts)       # the delta is queued; the collective is issued later, behind this event
+
+            def rest():
+                with torch.cuda.stream(self._xs):
+                    self._xs.wait_event(self._ev_snap)
+                    self.pending = (self._exchange(False), True)
+
+            self._deferred = rest
+            return
         work = self._exchange(blocking)
         self.pending = (work if not blocking else None, with_mine)
-        self.exchanges += 1
         if blocking:
             self._complete()
 
@@ -305,6 +336,7 @@ class ItemSync:
                     got = e.train_range(lo, hi, want_loss=self.track_loss)
                 else:
                     got = e.train_range(lo, hi, self.negatives[lo:hi], want_loss=self.track_loss)
+                self._issue()                    # the window's kernel is queued: now the host has time for the collective
                 if self.track_loss:
                     loss_sum += got
             self.sync(last=(w == n_windows - 1))

@@ -579,6 +579,7 @@ template <int CAP, bool DBUF, int AREG> __global__ __launch_bounds__(256, 1) voi
     __syncthreads();
 
     uint32_t g = 0;
+    float thr_pending = -INFINITY;          // what the other item splits had published one tile ago (lanes < 32)
     for (uint32_t tile = t_begin; tile < t_end; ++tile)
     {
         const uint32_t i0 = tile * (uint32_t)TI;
@@ -708,18 +709,22 @@ template <int CAP, bool DBUF, int AREG> __global__ __launch_bounds__(256, 1) voi
         if (p.ablate == 2u) { if (lane == 0) s.qn[wave] = 0u; __builtin_amdgcn_wave_barrier(); }
         else if (s.qn[wave] != 0u) drain2(s, k, wave, lane);
 
-        // threshold exchange between the item splits of these users (see the 64 x 128 kernel)
+        // threshold exchange between the item splits of these users (see the 64 x 128 kernel) — without waiting for it: the
+        // value read from the other splits is consumed ONE TILE LATER (a bound that is a tile old is still a bound), so the
+        // global round trip (~1.5 us) hides behind the next tile's MFMAs instead of stalling the wave at every tile
         if (p.thr_shared && lane < 32 && ub + lane < p.rows)
         {
             const uint32_t u = (uint32_t)(wave * 32 + lane);
             const float mine = s.thr_v[u];
             float* gthr = p.thr_shared + ub + lane;
+            const float best = fmaxf(mine, thr_pending);
             if (mine > s.thr_sh[u])
             {
                 if (mine >= 0.0f) atomicMax(reinterpret_cast<int*>(gthr), __float_as_int(mine));
                 else atomicMin(reinterpret_cast<unsigned int*>(gthr), __float_as_uint(mine));
             }
-            s.thr_sh[u] = fmaxf(mine, __builtin_nontemporal_load(gthr));
+            s.thr_sh[u] = best;
+            thr_pending = __builtin_nontemporal_load(gthr);
         }
         __builtin_amdgcn_wave_barrier();
         __asm__ volatile("" ::: "memory");
