@@ -89,7 +89,7 @@ class ItemSync:
 
     def __init__(self, engine, item_w, world_size, refresh_interval=8192, sync_interactions=0, mode="sum", streams=0,
                  force_collective=False, mean_tensors=(), negatives=None, overlap=False, defer_final=False, dist=None,
-                 windows_per_epoch=0, collective="all_reduce", pipelined=True):
+                 windows_per_epoch=0, collective="all_reduce", pipelined=True, epochs_per_exchange=1):
         if dist is None:
             import torch.distributed as dist
         self.dist = dist
@@ -104,6 +104,8 @@ class ItemSync:
             sync_interactions = streams * refresh_interval
         self.window = max(1, int(sync_interactions))   # clamped to the LARGEST shard inside train_one_epoch (same on every rank)
         self.windows_per_epoch = int(windows_per_epoch)   # > 0: the largest shard is cut into this many equal windows instead
+        self.epochs_per_exchange = max(1, int(epochs_per_exchange))   # > 1: whole epochs between exchanges (finalize() closes)
+        self._epochs_done = 0
         self.force = bool(force_collective)     # run the collective path even with one rank (tests)
         if mode not in ("sum", "mean"):
             raise ValueError("mode must be 'sum' or 'mean'")
@@ -155,6 +157,7 @@ class ItemSync:
         return {"collective": name + (" + all_reduce(W0)" if self.mean_tensors else ""), "mode": self.mode,
                 "overlap": self.overlap, "pipelined": self.pipelined, "fused_delta_apply_kernels": bool(self.native),
                 "window_interactions_per_gpu": getattr(self, "last_window", min(self.window, self.engine.data_rows)),
+                "epochs_per_exchange": self.epochs_per_exchange,
                 "exchanges": self.exchanges}
 
     # ---- the two element-wise passes --------------------------------------------------------------------------------
@@ -305,7 +308,7 @@ class ItemSync:
         if not self.active:
             return
         self._complete()
-        if self.defer_final:
+        if self.defer_final or self.epochs_per_exchange > 1:
             self._post(blocking=True)
 
     def train_one_epoch(self):
@@ -339,7 +342,10 @@ class ItemSync:
                 self._issue()                    # the window's kernel is queued: now the host has time for the collective
                 if self.track_loss:
                     loss_sum += got
+            if self.epochs_per_exchange > 1 and (w != n_windows - 1 or (self._epochs_done + 1) % self.epochs_per_exchange != 0):
+                continue                         # no exchange at this boundary (the same decision on every rank)
             self.sync(last=(w == n_windows - 1))
+        self._epochs_done += 1
         e.end_epoch()
         return loss_sum if self.track_loss else None
 

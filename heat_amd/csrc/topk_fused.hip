@@ -498,7 +498,7 @@ template <class Shared> __device__ __forceinline__ void store_slab2(Shared& s, i
 }
 
 // AREG = A registers per lane = k pairs the kernel can hold (emb_dim <= 2 * AREG)
-template <int CAP, bool DBUF, int AREG> __global__ __launch_bounds__(256, 1) void topk_fused2_kernel(FusedArgs p)
+template <int CAP, bool DBUF, int AREG> __global__ __launch_bounds__(256, DBUF ? 1 : 2) void topk_fused2_kernel(FusedArgs p)
 {
     typedef Shared2T<CAP, DBUF> Shared;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem2[];
@@ -579,7 +579,6 @@ template <int CAP, bool DBUF, int AREG> __global__ __launch_bounds__(256, 1) voi
     __syncthreads();
 
     uint32_t g = 0;
-    float thr_pending = -INFINITY;          // what the other item splits had published one tile ago (lanes < 32)
     for (uint32_t tile = t_begin; tile < t_end; ++tile)
     {
         const uint32_t i0 = tile * (uint32_t)TI;
@@ -709,22 +708,18 @@ template <int CAP, bool DBUF, int AREG> __global__ __launch_bounds__(256, 1) voi
         if (p.ablate == 2u) { if (lane == 0) s.qn[wave] = 0u; __builtin_amdgcn_wave_barrier(); }
         else if (s.qn[wave] != 0u) drain2(s, k, wave, lane);
 
-        // threshold exchange between the item splits of these users (see the 64 x 128 kernel) — without waiting for it: the
-        // value read from the other splits is consumed ONE TILE LATER (a bound that is a tile old is still a bound), so the
-        // global round trip (~1.5 us) hides behind the next tile's MFMAs instead of stalling the wave at every tile
+        // threshold exchange between the item splits of these users (see the 64 x 128 kernel)
         if (p.thr_shared && lane < 32 && ub + lane < p.rows)
         {
             const uint32_t u = (uint32_t)(wave * 32 + lane);
             const float mine = s.thr_v[u];
             float* gthr = p.thr_shared + ub + lane;
-            const float best = fmaxf(mine, thr_pending);
             if (mine > s.thr_sh[u])
             {
                 if (mine >= 0.0f) atomicMax(reinterpret_cast<int*>(gthr), __float_as_int(mine));
                 else atomicMin(reinterpret_cast<unsigned int*>(gthr), __float_as_uint(mine));
             }
-            s.thr_sh[u] = best;
-            thr_pending = __builtin_nontemporal_load(gthr);
+            s.thr_sh[u] = fmaxf(mine, __builtin_nontemporal_load(gthr));
         }
         __builtin_amdgcn_wave_barrier();
         __asm__ volatile("" ::: "memory");
@@ -774,6 +769,13 @@ __global__ __launch_bounds__(64) void topk_merge_kernel(const float* part_v, con
 } // namespace
 
 // which kernel runs: the 128 x 128 one (round 3) unless HEAT_CF_TOPK_KERNEL=v1 asks for the 64 x 128 one (A/B runs)
+// experiments: HEAT_CF_TOPK_WGS=2 runs the 128-user kernel with a single-buffered item slab, two workgroups per compute unit
+static bool two_wgs()
+{
+    const char* e = std::getenv("HEAT_CF_TOPK_WGS");
+    return e && e[0] == '2';
+}
+
 static bool use_v2()
 {
     const char* e = std::getenv("HEAT_CF_TOPK_KERNEL");
@@ -787,7 +789,7 @@ static bool use_v2()
 uint32_t topk_fused_splits(uint32_t rows, uint32_t num_items, uint32_t cus)
 {
     const bool v2 = use_v2();
-    const uint32_t tu = v2 ? (uint32_t)TU2 : (uint32_t)TU, slots = v2 ? cus : 2u * cus;
+    const uint32_t tu = v2 ? (uint32_t)TU2 : (uint32_t)TU, slots = (v2 && !two_wgs()) ? cus : 2u * cus;
     const uint32_t nblocks = (rows + tu - 1) / tu, ntiles = (num_items + TI - 1) / TI;
     if (nblocks == 0 || ntiles == 0 || slots == 0) return 1;
     uint32_t best = 1;
@@ -839,7 +841,9 @@ hipError_t launch_topk_fused(const float* user_rows, const float* item_w, uint32
     if (use_v2() && emb_dim <= 256)
     {
         // list slots 32 / 64 by k; A registers 32 / 64 / 128 by emb_dim; the item slab is double-buffered where LDS allows
-        if (k <= 32)
+        if (k <= 32 && emb_dim <= 64 && two_wgs())
+            err = launch_v2<32, false, 32>(p, splits, s);
+        else if (k <= 32)
             err = emb_dim <= 64 ? launch_v2<32, true, 32>(p, splits, s)
                 : emb_dim <= 128 ? launch_v2<32, true, 64>(p, splits, s) : launch_v2<32, true, 128>(p, splits, s);
         else

@@ -11,7 +11,7 @@ from heat_amd.cf.distributed import shard_bounds, shard_clicks
 
 
 def train_sharded(graph, uw0, iw0, *, num_negs, world, epochs, windows_per_epoch=1, overlap=False, seed=2022, scale=1.0,
-                  **cfg):
+                  exchange_every=1, defer_final=False, **cfg):
     """Returns (user table [num_users, d], item table [num_items, d], mean loss per epoch) after `epochs` epochs."""
     import torch
     dev = torch.device("cuda", 0)
@@ -58,7 +58,7 @@ def train_sharded(graph, uw0, iw0, *, num_negs, world, epochs, windows_per_epoch
                     r["pending"] = True
 
         losses = []
-        for _ in range(epochs):
+        for epoch in range(epochs):
             tot = 0.0
             for r in ranks:
                 r["eng"].begin_epoch()
@@ -67,10 +67,18 @@ def train_sharded(graph, uw0, iw0, *, num_negs, world, epochs, windows_per_epoch
                     lo, hi = min(r["n"], w * window), min(r["n"], (w + 1) * window)
                     if hi > lo:
                         tot += r["eng"].train_range(lo, hi, want_loss=True)
-                post(blocking=(not overlap) or w == windows_per_epoch - 1)
+                # exchange_every > 1: the exchange only every so many epochs (ItemSync(epochs_per_exchange=...)), and a closing one
+                final = epoch == epochs - 1 and w == windows_per_epoch - 1
+                if exchange_every > 1 and not final and ((epoch + 1) % exchange_every != 0 or w != windows_per_epoch - 1):
+                    continue
+                # defer_final (what bench.py runs in steady state): the closing exchange of an epoch is overlapped too, the other
+                # ranks' deltas of an epoch's last window arrive during the next epoch; the very last one is completed
+                post(blocking=(not overlap) or (w == windows_per_epoch - 1 and (final or not defer_final)))
             for r in ranks:
                 r["eng"].end_epoch()
             losses.append(tot / graph.clicks.shape[0])
+        if defer_final and overlap and ranks[0]["pending"]:
+            post(blocking=True)                     # ItemSync.finalize()
         side.synchronize()
         name = ranks[0]["eng"].kernel_name
         for a, b in zip(ranks[:-1], ranks[1:]):

@@ -23,6 +23,8 @@ ap.add_argument("--world", type=str, default="8")
 ap.add_argument("--windows", type=str, default="1")
 ap.add_argument("--overlap", type=str, default="0")
 ap.add_argument("--streams", type=str, default="0", help="streams per shard engine (0 = the engine's own plan)")
+ap.add_argument("--exchange-every", type=int, default=1, help="item-table exchange only every so many epochs")
+ap.add_argument("--defer-final", type=int, default=0, help="1: the closing exchange of an epoch overlaps the next epoch (bench.py's steady state)")
 ap.add_argument("--clip", type=float, default=1.0)
 ap.add_argument("--seeds", type=str, default="2022")
 ap.add_argument("--oracle-runs", type=int, default=1)
@@ -60,7 +62,8 @@ for seed in [int(x) for x in args.seeds.split(",")]:
                     t0 = time.time()
                     su, si, sl, name = train_sharded(g, uw0, iw0, num_negs=N, world=world, epochs=args.epochs,
                                                      windows_per_epoch=windows, overlap=bool(overlap), seed=seed,
-                                                     clip_val=args.clip, num_streams=streams)
+                                                     clip_val=args.clip, num_streams=streams, exchange_every=args.exchange_every,
+                                                     defer_final=bool(args.defer_final))
                     print(f"SHARDED seed={seed} world={world} windows/epoch={windows} overlap={overlap} {name}: "
                           f"losses={[round(x, 4) for x in sl]} ({time.time() - t0:.1f}s)", flush=True)
                     evaluate(su, si, f"world={world} streams={streams} windows={windows} overlap={overlap}")
