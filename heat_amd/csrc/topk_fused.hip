@@ -843,6 +843,8 @@ hipError_t launch_topk_fused(const float* user_rows, const float* item_w, uint32
         // list slots 32 / 64 by k; A registers 32 / 64 / 128 by emb_dim; the item slab is double-buffered where LDS allows
         if (k <= 32 && emb_dim <= 64 && two_wgs())
             err = launch_v2<32, false, 32>(p, splits, s);
+        else if (k <= 32 && emb_dim <= 128 && two_wgs())
+            err = launch_v2<32, false, 64>(p, splits, s);
         else if (k <= 32)
             err = emb_dim <= 64 ? launch_v2<32, true, 32>(p, splits, s)
                 : emb_dim <= 128 ? launch_v2<32, true, 64>(p, splits, s) : launch_v2<32, true, 128>(p, splits, s);
