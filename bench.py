@@ -15,10 +15,12 @@ N = 1  : BASELINE.json configs[1].  Tables and the interaction list are resident
          buffers written back every epoch: `value_host_mode`) and the CPU oracle timed on this box's host cores.
 N > 1  : BASELINE.json configs[3]: the SAME graph partitioned by user range (cf/main.py:51-57; ranges cut at equal
          interaction counts), one shard per rank, item table replicated, item-table deltas all-reduced over RCCL/xGMI
-         (heat_amd.cf.distributed.ItemSync).  Two legs over the same K steps: every exchange completed before the next
-         window (`item_sync_blocking`), then the all-reduce overlapped with the next window — `value` is the second when it
-         finishes (a watchdog falls back to the first).  `value` = the graph's interactions x steps / time: strong scaling.
-         Extra keys: the direct exchange, the literal "all-reduce every 8192 steps" window, a short weak-scaling leg.
+         (heat_amd.cf.distributed.ItemSync), one exchange per epoch (one every two epochs from 8 GPUs on: the exchange
+         window stays at about half a million interactions per GPU; Recall-validated).  Two legs over the
+         same K steps: every exchange completed before training goes on (`item_sync_blocking`), then the all-reduce
+         overlapped with the next window — `value` is the second when it finishes (a watchdog falls back to the first).
+         `value` = the graph's interactions x steps / time: strong scaling.  Extra keys: the direct exchange, the pipelined
+         form, one exchange per epoch, the literal "all-reduce every 8192 steps" window, a short weak-scaling leg.
 Rank 0 prints ONE JSON line.
 """
 import argparse
@@ -297,7 +299,8 @@ def main():
     ap.add_argument("--shape", default="amazonbooks")
     ap.add_argument("--update-mode", type=int, default=0, help="HEAT_CF_UPDATE_* (0 = engine default: AUTO)")
     ap.add_argument("--num-streams", type=int, default=0)
-    ap.add_argument("--windows", type=int, default=0, help="N>1: item-table exchanges per epoch (0 = default, see DESIGN.md section 5)")
+    ap.add_argument("--windows", type=int, default=0, help="N>1: item-table exchanges per epoch (0 = default: 1, see DESIGN.md section 5)")
+    ap.add_argument("--epochs-per-exchange", type=int, default=0, help="N>1: whole epochs between item-table exchanges (0 = default: 1, from 8 GPUs on 2)")
     ap.add_argument("--no-overlap", action="store_true", help="N>1: complete every exchange before the next window")
     ap.add_argument("--collective", default=os.environ.get("HEAT_BENCH_COLLECTIVE", "all_reduce"), choices=("all_reduce", "direct"),
                     help="N>1: how the item-table deltas are summed over the ranks (heat_amd.cf.distributed.ItemSync)")
@@ -446,9 +449,17 @@ def main():
         eng.train_range(0, my_T, want_loss=False)
         eng.end_epoch()
 
-    def sync_kwargs(overlap):
-        return dict(windows_per_epoch=args.windows or 2, mode="sum", force_collective=force_sync, overlap=overlap,
-                    defer_final=overlap, collective=args.collective)
+    # Exchange schedule (a measured choice): ONE exchange per epoch up to 4 GPUs, one every TWO epochs from
+    # 8 GPUs on — the exchange window is held at about half a million interactions per GPU (AmazonBooks shape: 595 k at 4 GPUs,
+    # 2 x 298 k at 8); every schedule bench.py can run holds Recall@20 / NDCG@20 within 1e-3 of single-engine training
+    # (tests/test_gpu_parity.py::test_eight_user_shards_match_single_engine_recall_ndcg)
+    epe = args.epochs_per_exchange or (2 if world >= 8 else 1)
+
+    def sync_kwargs(overlap, **over):
+        kw = dict(windows_per_epoch=args.windows or 1, mode="sum", force_collective=force_sync, overlap=overlap,
+                  defer_final=overlap, collective=args.collective, epochs_per_exchange=epe, pipelined=False)
+        kw.update(over)
+        return kw
 
     def line(value_elapsed, steps, trainer, kernel_ms, launches, note=None):
         traffic, traffic_src = (None, None)
@@ -541,28 +552,32 @@ def main():
                     lambda: line(head[0], args.steps, head[1], head[2], head[3], note="an extra leg did not finish: cut short"))
         # (a) the literal reading of configs[3]: one all-reduce every 8192 interactions per GPU
         lit = ItemSync(eng, item_w, world, sync_interactions=8192, mode="sum", overlap=not args.no_overlap,
-                       defer_final=not args.no_overlap)
+                       defer_final=not args.no_overlap, pipelined=False)
         k = max(1, min(3, args.steps))
         el = timed(lit.train_one_epoch, k, 1, lit.finalize)
         extra["item_sync_every_8192"] = {"value": T * k / el, "unit": "samples/s", "ms_per_step": el / k * 1e3, "steps": k,
                                          "item_sync": lit.describe(), "exchanges_per_epoch_per_gpu": -(-(T // world) // 8192)}
-        # (a') the headline schedule with the direct exchange (slices scattered to their owners, summed there, gathered
-        # back) instead of RCCL's all-reduce: which one the xGMI links prefer is measured here, not guessed
+        # (a') the headline schedule in its other forms, each over <= 10 steps: the direct exchange (slices scattered to their
+        # owners, summed there, gathered back) instead of RCCL's all-reduce; the pipelined form (one pass on the training
+        # stream, the rest on an exchange stream); one exchange per epoch where the headline runs one every two.  Which one the
+        # xGMI links and this node prefer is measured here, not guessed.
         alt_name = "all_reduce" if args.collective == "direct" else "direct"
-        try:
-            alt = ItemSync(eng, item_w, world, windows_per_epoch=args.windows or 2, mode="sum", overlap=not args.no_overlap,
-                           defer_final=not args.no_overlap, collective=alt_name)
-            k = max(1, min(10, args.steps))
-            el = timed(alt.train_one_epoch, k, 2, alt.finalize)
-            extra["item_sync_" + alt_name] = {"value": T * k / el, "unit": "samples/s", "ms_per_step": el / k * 1e3, "steps": k,
-                                              "item_sync": alt.describe()}
-        except Exception as err:      # an extra leg must not cost the headline line
-            extra["item_sync_" + alt_name] = {"error": repr(err)}
+        legs = [("item_sync_" + alt_name, dict(collective=alt_name)), ("item_sync_pipelined", dict(pipelined=True))]
+        if epe != 1:
+            legs.append(("item_sync_every_epoch", dict(epochs_per_exchange=1)))
+        for leg_name, over_kw in legs:
+            try:
+                alt = ItemSync(eng, item_w, world, **sync_kwargs(not args.no_overlap, **over_kw))
+                k = max(2, min(10, args.steps))
+                el = timed(alt.train_one_epoch, k, 2, alt.finalize)
+                extra[leg_name] = {"value": T * k / el, "unit": "samples/s", "ms_per_step": el / k * 1e3, "steps": k,
+                                   "item_sync": alt.describe()}
+            except Exception as err:      # an extra leg must not cost the headline line
+                extra[leg_name] = {"error": repr(err)}
         # (b) weak scaling: every rank its own AmazonBooks-shaped graph (different users, same item space)
         g2 = synthetic.make_graph(U, I, T, seed=2022 + 1000 * (rank + 1), with_test=False)
         eng2, item2 = build(g2.clicks, U, uw_h, (rank + 1) * T, None)
-        tr2 = ItemSync(eng2, item2, world, windows_per_epoch=args.windows or 2, mode="sum", overlap=not args.no_overlap,
-                       defer_final=not args.no_overlap)
+        tr2 = ItemSync(eng2, item2, world, **sync_kwargs(not args.no_overlap, epochs_per_exchange=1, force_collective=False))
         k = max(1, min(5, args.steps))
         el = timed(tr2.train_one_epoch, k, 1, tr2.finalize)
         extra["weak_scaling"] = {"value": world * T * k / el, "unit": "samples/s", "ms_per_step": el / k * 1e3, "steps": k,
