@@ -927,8 +927,8 @@ static int topk_fused(heat_cf_engine* e, uint64_t u_begin, uint64_t u_end, uint3
     const uint64_t panel = std::min<uint64_t>(nu, panel_cap);
     const uint32_t slots = e->cu_count;     // topk_fused_splits knows how many workgroups of its kernel a compute unit holds
     const uint64_t last = nu % panel ? nu % panel : panel;
-    const size_t part_elems = (size_t)k * std::max<uint64_t>(panel * topk_fused_splits((uint32_t)panel, (uint32_t)I, slots),
-                                                             last * topk_fused_splits((uint32_t)last, (uint32_t)I, slots));
+    const size_t part_elems = (size_t)k * std::max<uint64_t>(panel * topk_fused_splits((uint32_t)panel, (uint32_t)I, slots, (uint32_t)d, k),
+                                                             last * topk_fused_splits((uint32_t)last, (uint32_t)I, slots, (uint32_t)d, k));
     float*    d_pv = nullptr;
     float*    d_thr = nullptr;
     uint32_t* d_pi = nullptr;
@@ -1010,7 +1010,7 @@ static int topk_fused(heat_cf_engine* e, uint64_t u_begin, uint64_t u_end, uint3
                     err = sort_mask_rows(d_raw, d_items, (uint32_t)n_items, (uint32_t)rows, d_indptr, id_bits, d_temp, &need, e->stream);
             }
         }
-        const uint32_t splits = topk_fused_splits((uint32_t)rows, (uint32_t)I, slots);
+        const uint32_t splits = topk_fused_splits((uint32_t)rows, (uint32_t)I, slots, (uint32_t)d, k);
         const auto t1 = now();
         ms_check += ms(t0, t1);
         if (err == hipSuccess)

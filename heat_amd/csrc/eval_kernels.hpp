@@ -19,8 +19,8 @@ hipError_t launch_topk_rows(float* sim, uint32_t rows, uint32_t num_items, uint3
 // Fused path (topk_fused.hip): no score matrix; k <= TOPK_FUSED_MAX_K, emb_dim % 4 == 0, mask rows sorted ascending.
 #define TOPK_FUSED_MAX_K 64
 #define TOPK_FUSED_MAX_SPLITS 16
-// how many item-range splits to run for `rows` users on a chip with `cus` compute units
-uint32_t topk_fused_splits(uint32_t rows, uint32_t num_items, uint32_t cus);
+// how many item-range splits to run for `rows` users on a chip with `cus` compute units (depends on the kernel (emb_dim, k) select)
+uint32_t topk_fused_splits(uint32_t rows, uint32_t num_items, uint32_t cus, uint32_t emb_dim, uint32_t k);
 // part_v / part_i: scratch [splits, rows, k]; thr_shared: scratch [rows] (threshold exchange between item splits);
 // topk: DEVICE [rows, k]; indptr (relative, [rows+1]) / items may be NULL
 hipError_t launch_topk_fused(const float* user_rows, const float* item_w, uint32_t rows, uint32_t num_items,

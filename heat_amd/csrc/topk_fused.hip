@@ -448,43 +448,8 @@ template <int CAP, bool DBUF> struct __attribute__((aligned(16))) Shared2T
     uint32_t qn[4];
 };
 
-// One candidate of local user u, handled by the whole wave (lane l < k owns list slot l): as insert() above, plus what the
-// queueing lanes no longer check — a train item of the current tile (bit item - i0 of the user's mask) scores -inf, and
-// a score below what another item split already guarantees is dropped.
-template <class Shared>
-__device__ __forceinline__ void insert2(Shared& s, uint32_t u, uint32_t item, float v, uint32_t k, int lane, uint32_t i0)
-{
-    const bool have = (uint32_t)lane < k;
-    const uint32_t bit = item - i0;
-    const uint32_t mword = s.mbits[u][bit >> 5];
-    const float    tv = s.thr_v[u];
-    const float    tsh = s.thr_sh[u];
-    const uint32_t ti = s.thr_i[u];
-    const float    ev = have ? s.topv[u][lane] : 0.0f;
-    const uint32_t ei = have ? s.topi[u][lane] : 0u;
-    const float    pv = (have && lane > 0) ? s.topv[u][lane - 1] : 0.0f;
-    const uint32_t pi = (have && lane > 0) ? s.topi[u][lane - 1] : 0u;
-    if ((mword >> (bit & 31u)) & 1u) v = -INFINITY;
-    if (v != v || v < tsh || !ahead(v, item, tv, ti)) return;
-    const uint32_t pos = (uint32_t)__popcll(__ballot(have && ahead(ev, ei, v, item)));
-    if (have && (uint32_t)lane >= pos)
-    {
-        const float    nv = (uint32_t)lane == pos ? v : pv;
-        const uint32_t ni = (uint32_t)lane == pos ? item : pi;
-        s.topv[u][lane] = nv;
-        s.topi[u][lane] = ni;
-        if ((uint32_t)lane == k - 1)
-        {
-            s.thr_v[u] = nv;
-            s.thr_i[u] = ni;
-        }
-    }
-    __builtin_amdgcn_wave_barrier();
-    __asm__ volatile("" ::: "memory");
-}
-
 // every wave empties ITS queue into the lists of ITS users: no other wave ever touches either
-template <class Shared> __device__ __forceinline__ void drain2(Shared& s, uint32_t k, int wave, int lane, uint32_t i0)
+template <class Shared> __device__ __forceinline__ void drain2(Shared& s, uint32_t k, int wave, int lane)
 {
     const uint32_t n = min(s.qn[wave], (uint32_t)QW2);
     for (uint32_t base = 0; base < n; base += 64)
@@ -495,8 +460,8 @@ template <class Shared> __device__ __forceinline__ void drain2(Shared& s, uint32
         const float    cv = e < n ? s.qv[wave][e] : 0.0f;
         const int cnt = (int)min(64u, n - base);
         for (int j = 0; j < cnt; ++j)
-            insert2(s, (uint32_t)__builtin_amdgcn_readlane((int)cu, j), (uint32_t)__builtin_amdgcn_readlane((int)ci, j),
-                    __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cv), j)), k, lane, i0);
+            insert(s, (uint32_t)__builtin_amdgcn_readlane((int)cu, j), (uint32_t)__builtin_amdgcn_readlane((int)ci, j),
+                   __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cv), j)), k, lane);
     }
     if (lane == 0) s.qn[wave] = 0u;
     __builtin_amdgcn_wave_barrier();
@@ -682,65 +647,66 @@ template <int CAP, bool DBUF, int AREG> __global__ __launch_bounds__(256, DBUF ?
         }
 
         // ---- selection, wave-local: lane's results acc[c][r] = user ub + 8 (r / 4) + 4 h + (r % 4), item i0 + 32 c + n
-        // Filter and queue in one static sweep over the 64 (column, row) pairs: a pair none of whose 64 scores reaches its
-        // users' thresholds costs a compare and a ballot; one that does writes its hits straight from their accumulator
-        // register to the wave's queue at tail + (hits in lower lanes) — the tail is a scalar, there is no LDS atomic, no
-        // dependent round trip and no register-select chain.  Train items (-inf, metrics.py:24) are recognised at insertion.
-        float thr[16];
-        auto load_thresholds = [&]() __attribute__((always_inline))
+        uint32_t cand[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
         {
+            const f4 tl = *(const f4*)&s.thr_v[wave * 32 + 8 * q + 4 * h];
+            const f4 ts = *(const f4*)&s.thr_sh[wave * 32 + 8 * q + 4 * h];
+            const f4 t4 = f4{fmaxf(tl[0], ts[0]), fmaxf(tl[1], ts[1]), fmaxf(tl[2], ts[2]), fmaxf(tl[3], ts[3])};
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
+            for (int j = 0; j < 4; ++j)
             {
-                const f4 tl = *(const f4*)&s.thr_v[wave * 32 + 8 * q + 4 * h];
-                const f4 ts = *(const f4*)&s.thr_sh[wave * 32 + 8 * q + 4 * h];
+                const int r = 4 * q + j;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) thr[4 * q + j] = fmaxf(tl[j], ts[j]);
+                for (int c = 0; c < 4; ++c) cand[c] |= (!(acc[c][r] < t4[j]) ? 1u : 0u) << r;
             }
-        };
-        load_thresholds();
-        uint32_t qtail = 0u;                                                  // wave-uniform
+        }
+        if (p.ablate == 1u && acc[0][0] != 12345.678f) cand[0] = cand[1] = cand[2] = cand[3] = 0u;
 #pragma unroll
         for (int c = 0; c < 4; ++c)
         {
             const uint32_t item = i0 + (uint32_t)(32 * c + n);
-            const bool item_ok = item < p.num_items && p.ablate != 1u;
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
+            uint32_t todo = item < p.num_items ? (cand[c] & ulive) : 0u;
+            while (__ballot(todo != 0u) != 0ull)
             {
-                const bool hit = item_ok && ((ulive >> r) & 1u) && !(acc[c][r] < thr[r]);
-                const uint64_t m = __ballot(hit);
-                if (m != 0ull)
+                bool full = false;
+                if (todo != 0u)
                 {
-                    const uint32_t cnt = (uint32_t)__popcll(m);
-                    if (qtail + cnt > (uint32_t)QW2)                          // first tiles: make room, against fresh thresholds
+                    const int r = __builtin_ctz(todo);
+                    const uint32_t u = (uint32_t)(wave * 32 + 8 * (r >> 2) + 4 * h + (r & 3));
+                    float v = 0.0f;
+#pragma unroll
+                    for (int r2 = 0; r2 < 16; ++r2)
+                        if (r2 == r) v = acc[c][r2];
+                    if ((s.mbits[u][c] >> n) & 1u) v = -INFINITY;             // a train item scores -inf (metrics.py:24)
+                    bool done = true;
+                    if (v == v && !(v < s.thr_v[u]) && !(v < s.thr_sh[u]))
                     {
-                        if (lane == 0) s.qn[wave] = qtail;
-                        __builtin_amdgcn_wave_barrier();
-                        drain2(s, k, wave, lane, i0);
-                        qtail = 0u;
-                        load_thresholds();
+                        const uint32_t slot = atomicAdd(&s.qn[wave], 1u);
+                        if (slot < (uint32_t)QW2)
+                        {
+                            s.qv[wave][slot] = v;
+                            s.qi[wave][slot] = item;
+                            s.qu[wave][slot] = (uint8_t)u;
+                        }
+                        else
+                        {
+                            done = false;                                     // queue full (first tiles): drain, then try again
+                            full = true;
+                        }
                     }
-                    const bool still = hit && !(acc[c][r] < thr[r]);
-                    const uint64_t m2 = __ballot(still);
-                    const uint32_t pos = qtail + (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(m2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m2, 0u));
-                    if (still)
-                    {
-                        s.qv[wave][pos] = acc[c][r];
-                        s.qi[wave][pos] = item;
-                        s.qu[wave][pos] = (uint8_t)(wave * 32 + 8 * (r >> 2) + 4 * h + (r & 3));
-                    }
-                    qtail += (uint32_t)__popcll(m2);
+                    if (done) todo &= todo - 1u;
+                }
+                if (__ballot(full) != 0ull)
+                {
+                    if (p.ablate == 2u) { if (lane == 0) s.qn[wave] = 0u; __builtin_amdgcn_wave_barrier(); }
+                    else drain2(s, k, wave, lane);                            // raises the thresholds the retries are checked against
                 }
             }
         }
-        if (qtail != 0u)
-        {
-            if (lane == 0) s.qn[wave] = qtail;
-            __builtin_amdgcn_wave_barrier();
-            __asm__ volatile("" ::: "memory");
-            drain2(s, k, wave, lane, i0);
-        }
+        if (p.ablate == 2u) { if (lane == 0) s.qn[wave] = 0u; __builtin_amdgcn_wave_barrier(); }
+        else if (s.qn[wave] != 0u) drain2(s, k, wave, lane);
 
         // threshold exchange between the item splits of these users (see the 64 x 128 kernel)
         if (p.thr_shared && lane < 32 && ub + lane < p.rows)
@@ -803,17 +769,16 @@ __global__ __launch_bounds__(64) void topk_merge_kernel(const float* part_v, con
 } // namespace
 
 // which kernel runs: the 128 x 128 one (round 3) unless HEAT_CF_TOPK_KERNEL=v1 asks for the 64 x 128 one (A/B runs)
-// experiments: HEAT_CF_TOPK_WGS=2 runs the 128-user kernel with a single-buffered item slab, two workgroups per compute unit
-static bool two_wgs()
-{
-    const char* e = std::getenv("HEAT_CF_TOPK_WGS");
-    return e && e[0] == '2';
-}
-
-static bool use_v2()
+// Which kernel runs.  The 128-user kernel (two workgroups per compute unit, item slab single-buffered, 32-slot lists, the
+// whole user panel of a wave in 32 registers) is compiled for k <= 32 and emb_dim <= 64, where it measured faster
+// (AmazonBooks shape top-20: 10.4 ms against 11.9); everything else runs the 64-user kernel, which stays faster there
+// (its one- and two-workgroup 128-user twins were measured at emb_dim 128 / 256 and k = 50 and lost by 4-25 %).
+// HEAT_CF_TOPK_KERNEL=v1 forces the 64-user kernel (A/B runs).
+static bool use_v2(uint32_t emb_dim, uint32_t k)
 {
     const char* e = std::getenv("HEAT_CF_TOPK_KERNEL");
-    return !(e && std::strcmp(e, "v1") == 0);
+    if (e && std::strcmp(e, "v1") == 0) return false;
+    return k <= 32u && emb_dim <= 64u;
 }
 
 // Item-range splits per user block for a chip with `cus` compute units.  Workgroups are dispatched as slots free up, so a
@@ -822,10 +787,9 @@ static bool use_v2()
 // candidate, and of the first 128 items about k + k ln(128 / k) per user are inserted — measured, about 40 tiles' worth of
 // time per split at k = 20.  So fewer, longer splits are preferred unless they leave slots empty: AmazonBooks shape on the
 // 128-user kernel (412 user blocks, 512 slots) runs ONE split per block, the 64-user kernel (823 blocks) three.
-uint32_t topk_fused_splits(uint32_t rows, uint32_t num_items, uint32_t cus)
+uint32_t topk_fused_splits(uint32_t rows, uint32_t num_items, uint32_t cus, uint32_t emb_dim, uint32_t k)
 {
-    const bool v2 = use_v2();
-    const uint32_t tu = v2 ? (uint32_t)TU2 : (uint32_t)TU, slots = (v2 && !two_wgs()) ? cus : 2u * cus;
+    const uint32_t tu = use_v2(emb_dim, k) ? (uint32_t)TU2 : (uint32_t)TU, slots = 2u * cus;   // both kernels: two workgroups per CU
     const uint32_t nblocks = (rows + tu - 1) / tu, ntiles = (num_items + TI - 1) / TI;
     if (nblocks == 0 || ntiles == 0 || slots == 0) return 1;
     if (const char* e = std::getenv("HEAT_CF_TOPK_SPLITS"))      // experiments: force the split count (clamped to what is legal)
@@ -882,19 +846,9 @@ hipError_t launch_topk_fused(const float* user_rows, const float* item_w, uint32
         if (e0 != hipSuccess) return e0;
     }
     hipError_t err;
-    if (use_v2() && emb_dim <= 256)
+    if (use_v2(emb_dim, k))
     {
-        // list slots 32 / 64 by k; A registers 32 / 64 / 128 by emb_dim; the item slab is double-buffered where LDS allows
-        if (k <= 32 && emb_dim <= 64 && two_wgs())
-            err = launch_v2<32, false, 32>(p, splits, s);
-        else if (k <= 32 && emb_dim <= 128 && two_wgs())
-            err = launch_v2<32, false, 64>(p, splits, s);
-        else if (k <= 32)
-            err = emb_dim <= 64 ? launch_v2<32, true, 32>(p, splits, s)
-                : emb_dim <= 128 ? launch_v2<32, true, 64>(p, splits, s) : launch_v2<32, true, 128>(p, splits, s);
-        else
-            err = emb_dim <= 64 ? launch_v2<64, true, 32>(p, splits, s)
-                : emb_dim <= 128 ? launch_v2<64, true, 64>(p, splits, s) : launch_v2<64, true, 128>(p, splits, s);
+        err = launch_v2<32, false, 32>(p, splits, s);
     }
     else
     {
