@@ -147,7 +147,7 @@ def hbm_resident_leg(dev, stream, interactions, steps=2):
     dt = time.perf_counter() - t0
     kernel_ms, launches = eng.kernel_time()
     B, B_rd = 16 * d * (N + 2) + 16, 8 * d * (N + 2) + 16
-    traffic, src = replayed_traffic("r02_pmc_traffic_hbm.json", eng.kernel_name)
+    traffic, src = replayed_traffic("r03_pmc_traffic_hbm.json", eng.kernel_name)
     out = roofline(B, B_rd, T * steps, kernel_ms, launches, 2 * (U + I) * d * 4, traffic, src)
     out["workload"] = (f"synthetic 10M x 1M, d={d}, negs={N}: {T} interactions per launch = {T // 20} users spread over the whole "
                        f"table x 20 interactions each, a sample of the 200M list (a full pass is 83.6 TB of algorithmic traffic)")
@@ -464,7 +464,7 @@ def main():
     def line(value_elapsed, steps, trainer, kernel_ms, launches, note=None):
         traffic, traffic_src = (None, None)
         if world == 1 and args.shape in ("amazonbooks", "yelp18") and args.update_mode == 0 and args.num_streams == 0:
-            traffic, traffic_src = replayed_traffic("r02_pmc_traffic.json" if args.shape == "amazonbooks" else
+            traffic, traffic_src = replayed_traffic("r03_pmc_traffic.json" if args.shape == "amazonbooks" else
                                                     "r02_pmc_traffic_yelp18.json", eng.kernel_name)
         out = {
             "metric": "positive-samples/sec/node (AmazonBooks d=64, negs=16)" if args.shape == "amazonbooks"

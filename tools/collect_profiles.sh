@@ -1,7 +1,7 @@
 # Copies the summaries of tools/final_profile.sh (gpurun_out/final/, scratch) into profiles/ under this round's names and
 # derives the per-launch memory-side traffic from the two PMC passes.   usage: bash tools/collect_profiles.sh r02
 set -e
-r=${1:-r02}; o=gpurun_out/final; p=profiles
+r=${1:-r03}; o=gpurun_out/final; p=profiles
 newest() { ls -t $1 | head -1; }
 cp $o/bench_n1.json $p/${r}_bench_n1.json
 cp $o/bench_under_rocprof.json $p/${r}_bench_under_rocprof.json
@@ -18,6 +18,11 @@ cp $o/bench_gowalla.json $p/${r}_bench_gowalla.json
 cp $o/bench_gowalla_pr1.json $p/${r}_bench_gowalla_pr1.json
 cp $o/bench_forcesync.json $p/${r}_bench_forcesync.json
 cp $(newest "$o/prof_topk/*/*_kernel_stats.csv") $p/${r}_topk_kernel_stats.csv
+cp $(newest "$o/prof_accl/*/*_kernel_stats.csv") $p/${r}_accl_kernel_stats.csv
+cp $(newest "$o/pmc_fetch_accl/*/*_counter_collection.csv") $p/${r}_pmc_fetch_accl_counter_collection.csv
+cp $(newest "$o/pmc_write_accl/*/*_counter_collection.csv") $p/${r}_pmc_write_accl_counter_collection.csv
+cp $o/accl_under_rocprof.txt $p/${r}_accl_quick_bench.txt
+cp $o/shard_bench_exchange_modes.txt $p/${r}_shard_bench_exchange_modes.txt
 python - <<PY
 import json, subprocess, sys
 for tag, bench in (("", "$o/bench_n1.json"), ("_hbm", "$o/bench_hbm_under_rocprof.json")):
@@ -31,3 +36,17 @@ for tag, bench in (("", "$o/bench_n1.json"), ("_hbm", "$o/bench_hbm_under_rocpro
     t = json.load(open("$p/${r}_pmc_traffic%s.json" % tag))
     print(tag or "headline", kernel, "traffic/algorithmic =", round(t["traffic_over_algorithmic"], 4))
 PY
+python - <<PY
+# ACCL: traffic of the aggregation kernel from its own two PMC passes; algorithmic bytes from quick_bench's header line
+import json, re, subprocess, sys
+txt = open("$o/accl_under_rocprof.txt").read()
+m = re.search(r"n=(\d+) d=(\d+) N=(\d+) B/sample=(\d+)", txt)
+n, B = int(m.group(1)), int(m.group(4))
+kern = re.search(r"kernel=(\S+)", txt).group(1)
+subprocess.check_call([sys.executable, "tools/pmc_traffic.py", "$p/${r}_pmc_fetch_accl_counter_collection.csv",
+                       "$p/${r}_pmc_write_accl_counter_collection.csv", "$p/${r}_pmc_traffic_accl.json", kern, str(n), str(B),
+                       "AmazonBooks shape with behaviour aggregation (histories of up to 100 items)"], stdout=subprocess.DEVNULL)
+t = json.load(open("$p/${r}_pmc_traffic_accl.json"))
+print("accl", kern, "traffic/algorithmic =", round(t["traffic_over_algorithmic"], 4))
+PY
+
