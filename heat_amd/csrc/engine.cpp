@@ -159,13 +159,16 @@ int make_plan(const heat_cf_config* cfg, uint64_t data_rows, uint64_t fill, Plan
     //     400 streams = 0.68 is at the edge) — and only with the "late re-read" write-back of the negative rows; with
     //     the plain store (read-modify-write window = the whole interaction) the same shape holds the tolerance only up
     //     to 0.15 (85 streams; profiles/r02_yelp18_policy_sweep.txt);
-    //   * behaviour aggregation reads up to max_his history rows whose staleness enters the same way; its bound is the
-    //     round-1 one (AmazonBooks shape: Recall@20 within 1e-3 of the oracle up to 640 streams, -2e-3 at 1024).
+    //   * behaviour aggregation reads up to max_his history rows, which it never writes: they count at half weight
+    //     (AmazonBooks shape: 765 streams by this bound; measured: Recall@20 equal to the sequentially consistent model of
+    //     the reference at 438, 512 and 768 streams, -2e-3 at 1024; profiles/r03_accl_worker_count.txt).  In this mode the
+    //     stream count also moves the LOSS CURVE — in the reference's own algorithm, DESIGN.md section 3 — so the count the
+    //     chip holds resident (512 four-wave streams at AmazonBooks shape) is used, not more.
     const double rows_per_interaction = (double)(cfg->num_negs + 1);
     const bool wide = rows_per_interaction > 17.0;
     const bool can_reread = wide && !cfg->use_aggregator && coh == HEAT_CF_COHERENCE_DEVICE;
     double in_flight = 0.56;
-    if (cfg->use_aggregator) in_flight = 0.56 * std::min(1.0, 17.0 / (rows_per_interaction + (double)history_rows));
+    if (cfg->use_aggregator) in_flight = 0.56 * std::min(1.0, 17.0 / (rows_per_interaction + 0.5 * (double)history_rows));
     else if (wide) in_flight = can_reread ? 0.45 : 0.15;
     p->cap_items = (uint32_t)std::min<uint64_t>(0xFFFFFFFFull, (uint64_t)(in_flight * (double)cfg->num_items / rows_per_interaction));
     // A stream walks at least 256 consecutive interactions (half a `schedule(dynamic,512)` chunk of the reference,
@@ -190,10 +193,10 @@ int make_plan(const heat_cf_config* cfg, uint64_t data_rows, uint64_t fill, Plan
         p->binding = "resident workgroups";
     }
     // a few workgroups more than a whole number per compute unit would make those units the tail of the launch — for the
-    // multi-wave workgroups, which run at what the memory system sustains; a single-wave stream between 1x and 4x the
-    // CU count, and a behaviour-aggregation stream of any shape, is latency-bound and simply scales with the count
-    // (aggregation at AmazonBooks shape: 256 streams 55.5 ms per epoch, 438 streams 34.9 ms)
-    if (cus && p->nw > 1 && !cfg->use_aggregator && streams > cus && streams < 4ull * cus) streams -= streams % cus;
+    // multi-wave workgroups, which run at what a compute unit sustains; a single-wave stream between 1x and 4x the CU
+    // count is latency-bound and simply scales with the count.  Round 3: the four-wave aggregation workgroups belong to the
+    // first kind (AmazonBooks shape: 438 streams 25.8 ms per epoch, 512 = two per CU 22.4, 640 31.3, 768 26.1)
+    if (cus && p->nw > 1 && streams > cus && streams < 4ull * cus) streams -= streams % cus;
     if (streams < 1) streams = 1;
     if (cfg->num_streams)
     {
@@ -398,7 +401,6 @@ TrainArgs make_args(const heat_cf_engine* e, uint64_t begin, uint64_t end)
     a.refresh_interval = (uint32_t)std::max<uint64_t>(1, e->cfg.refresh_interval);
     a.upd_bits = (uint32_t)e->upd;
     a.align_cap = (e->upd & 0xF) == 0 ? 4096u : 0u; // overwrite mode keeps a user's run inside one stream; atomic modes need not
-    if (const char* ac = std::getenv("HEAT_CF_ALIGN_CAP")) a.align_cap = (uint32_t)std::strtoul(ac, nullptr, 10);   // experiments
     a.lr = e->lr;
     a.clip = e->cfg.clip_val;
     a.key = epoch_key(e->cfg.seed, e->epoch);

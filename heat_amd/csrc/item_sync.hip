@@ -14,8 +14,6 @@
 // delta moves 16 B per element (2 reads, 2 writes), apply 24 B (4 reads, 2 writes).
 #include "ccl_train.hpp"
 
-#include <cstdlib>
-
 namespace heatcf
 {
 
@@ -62,32 +60,22 @@ __global__ __launch_bounds__(256) void item_apply_exact_kernel(f4* __restrict__ 
 // apply of exchange k and delta of exchange k + 1 in ONE pass (the overlapped schedule runs them back to back at every window
 // boundary): W += s - mine ; ref += s ; mine = sum = W - ref  — 4 tables read, 4 written (187 MB at AmazonBooks shape)
 // instead of 234 MB in two launches; the same expressions in the same order, so the same bits.
-template <bool NT>
 __global__ __launch_bounds__(256) void item_apply_delta_kernel(f4* __restrict__ w, f4* __restrict__ ref, f4* __restrict__ sum,
                                                                f4* __restrict__ mine, float scale, size_t n4)
 {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride)
     {
-        // NT: the three exchange buffers are touched once per exchange — non-temporal accesses keep them from displacing the
-        // training tables in the caches (HEAT_CF_SYNC_NT=1, experiment)
-        const f4 s = scale * (NT ? __builtin_nontemporal_load(sum + i) : sum[i]);
-        const f4 wn = w[i] + (s - (NT ? __builtin_nontemporal_load(mine + i) : mine[i]));
-        const f4 rn = (NT ? __builtin_nontemporal_load(ref + i) : ref[i]) + s;
+        // (non-temporal accesses for the three exchange buffers were measured: no change — what an exchange costs the next
+        // training kernel is not these buffers displacing the tables)
+        const f4 s = scale * sum[i];
+        const f4 wn = w[i] + (s - mine[i]);
+        const f4 rn = ref[i] + s;
         const f4 d = wn - rn;
         w[i] = wn;
-        if (NT)
-        {
-            __builtin_nontemporal_store(rn, ref + i);
-            __builtin_nontemporal_store(d, mine + i);
-            __builtin_nontemporal_store(d, sum + i);
-        }
-        else
-        {
-            ref[i] = rn;
-            mine[i] = d;
-            sum[i] = d;
-        }
+        ref[i] = rn;
+        mine[i] = d;
+        sum[i] = d;
     }
 }
 
@@ -159,9 +147,7 @@ hipError_t launch_item_apply_delta(float* w, float* ref, float* sum, float* mine
 {
     const size_t n4 = n_floats / 4;
     if (n4 == 0) return hipSuccess;
-    static const bool nt = [] { const char* e = std::getenv("HEAT_CF_SYNC_NT"); return e && e[0] == '1'; }();
-    if (nt) hipLaunchKernelGGL(item_apply_delta_kernel<true>, dim3(stream_grid(n4)), dim3(256), 0, s, (f4*)w, (f4*)ref, (f4*)sum, (f4*)mine, scale, n4);
-    else hipLaunchKernelGGL(item_apply_delta_kernel<false>, dim3(stream_grid(n4)), dim3(256), 0, s, (f4*)w, (f4*)ref, (f4*)sum, (f4*)mine, scale, n4);
+    hipLaunchKernelGGL(item_apply_delta_kernel, dim3(stream_grid(n4)), dim3(256), 0, s, (f4*)w, (f4*)ref, (f4*)sum, (f4*)mine, scale, n4);
     return hipGetLastError();
 }
 

@@ -160,7 +160,6 @@ struct FusedArgs
     float*          thr_shared; // [rows]: max over the item splits of a user's k-th best score so far (-inf at launch)
     float*          part_v;   // [splits, rows, k]
     uint32_t*       part_i;
-    uint32_t        ablate;   // experiments (HEAT_CF_TOPK_ABLATE): 1 = no candidate ever, 2 = candidates queued but never inserted
 };
 
 // Registers of one slab in flight: two float4 of user row u0+sr and of item rows i0+sr, i0+64+sr at columns
@@ -410,46 +409,48 @@ template <int CAP> __global__ __launch_bounds__(256, 2) void topk_fused_kernel(F
     }
 }
 
-// ---- round 3: 128 users x 128 items per workgroup, every user owned by ONE wave ------------------------------------------
+// ---- round 3: 128 users x 128 items per workgroup, every user owned by ONE wave (k <= 32, emb_dim <= 64) ----------------
 // What the 64 x 128 kernel above spends beyond its arithmetic (profiles/r02_topk_sq_counters.txt: matrix pipe busy 3.9 of
 // 11.9 ms at AmazonBooks shape) is per-tile fixed cost: seven workgroup barriers, both operands restaged through LDS, and a
 // candidate path in which four waves push into each other's queues, meet at a barrier and insert one candidate per LDS
 // round trip.  This form removes the sharing instead of tuning it:
-//   * wave w owns users [32 w, 32 w + 32) of the tile and ALL 128 items: four 32 x 32 accumulators (one wave per SIMD
-//     reaches the f32 matrix rate with four independent accumulators, MI355X_MICROARCH.md 'Matrix cores');
+//   * wave w owns users [32 w, 32 w + 32) of the tile and ALL 128 items: four 32 x 32 accumulators;
 //   * the A operand (the wave's 32 user rows) never changes over the item loop: it lives in REGISTERS for the whole kernel
-//     (lane (n, h): U[32 w + n][2 kp + h], kp = 0 .. d/2) — no staging, no LDS reads, no barrier for it;
-//   * only the item slab goes through LDS (64 k-values x 128 items = 33.8 KB), double-buffered where it fits: ONE barrier
-//     per slab, the next slab's global loads in flight under the MFMAs;
+//     (lane (n, h): U[32 w + n][2 kp + h], kp = 0 .. d/2: 32 registers at emb_dim 64) — no staging, no LDS reads, no barrier;
+//   * only the item tile goes through LDS (128 items x 64 k-values = 33.8 KB): two barriers per tile instead of seven, the
+//     next tile's global loads in flight under the MFMAs;
 //   * selection is wave-local: a score that passes its user's threshold goes into the WAVE'S OWN queue (LDS atomic slot
 //     counter, all lanes in parallel) and the wave then inserts its queue into its users' sorted lists, one ballot +
-//     popcount insertion per candidate against the always-current threshold.  No workgroup barrier, no cross-wave traffic.
-//     (First form of this round: per-user append buffers merged by rank counting when full — the stale thresholds tripled
-//     the candidates and a 32-entry merge cost ~5000 cycles of ballot / popcount round trips: 14.5 ms against 11.9.)
+//     popcount insertion per candidate against the always-current threshold.  No workgroup barrier, no cross-wave traffic;
+//   * two workgroups per compute unit (79 KB of LDS, 256 registers each): one's selection runs under the other's MFMAs.
+// AmazonBooks shape top-20: 10.6 ms against 11.9 (profiles/r03_topk_kernel_stats.csv).  Measured on the way and removed
+// (DESIGN.md section 4): one workgroup per CU with the tile double-buffered, 13.7 ms; per-user append buffers merged by rank
+// counting, 14.5; threshold exchange consumed a tile late, 15.6; filter + queueing as one static sweep over the 64
+// (column, row) pairs, 25.  At k > 32 or emb_dim > 64 the 64-user kernel stays faster and keeps those shapes.
 // Scores, order and ids are those of the kernel above (same fmaf chain per score, same (score desc, id asc) comparator).
-constexpr int TU2 = 128;   // users per workgroup
-constexpr int KS2 = 64;    // k-values per item slab
+constexpr int TU2 = 128;          // users per workgroup
+constexpr int KP2 = 32;           // k pairs the kernel holds: emb_dim <= 64
+constexpr int CAP2 = 32;          // list slots per user: k <= 32
 constexpr int LDB2 = TI + 4;
+constexpr int QW2 = 256;          // candidate queue entries per wave
 
-constexpr int QW2 = 256;   // candidate queue entries per wave
-
-template <int CAP, bool DBUF> struct __attribute__((aligned(16))) Shared2T
+struct __attribute__((aligned(16))) Shared2
 {
-    float    b[DBUF ? 2 : 1][KS2 / 2][LDB2][2];   // [k pair][item][k parity]
-    float    topv[TU2][CAP];                      // per user: the k best so far, best first
-    uint32_t topi[TU2][CAP];
-    float    thr_v[TU2];                          // = entry k - 1, the one a candidate has to beat
-    float    thr_sh[TU2];                         // best k-th score any item split of these users has published
+    float    b[KP2][LDB2][2];             // the item tile: [k pair][item][k parity]
+    float    topv[TU2][CAP2];             // per user: the k best so far, best first
+    uint32_t topi[TU2][CAP2];
+    float    thr_v[TU2];                  // = entry k - 1, the one a candidate has to beat
+    float    thr_sh[TU2];                 // best k-th score any item split of these users has published
     uint32_t thr_i[TU2];
-    uint32_t mbits[TU2][4];                       // train items of the current tile
-    float    qv[4][QW2];                          // per wave: candidates of the current tile, in arrival order
+    uint32_t mbits[TU2][4];               // train items of the current tile
+    float    qv[4][QW2];                  // per wave: candidates of the current tile, in arrival order
     uint32_t qi[4][QW2];
     uint8_t  qu[4][QW2];
     uint32_t qn[4];
 };
 
 // every wave empties ITS queue into the lists of ITS users: no other wave ever touches either
-template <class Shared> __device__ __forceinline__ void drain2(Shared& s, uint32_t k, int wave, int lane)
+__device__ __forceinline__ void drain2(Shared2& s, uint32_t k, int wave, int lane)
 {
     const uint32_t n = min(s.qn[wave], (uint32_t)QW2);
     for (uint32_t base = 0; base < n; base += 64)
@@ -468,9 +469,9 @@ template <class Shared> __device__ __forceinline__ void drain2(Shared& s, uint32
     __asm__ volatile("" ::: "memory");
 }
 
-struct Slab2Regs { f4 v[8]; };   // thread (sr, sc): item rows sr and 64 + sr, columns sc*4 + 16 j (j < 4) of the slab
+struct Tile2Regs { f4 v[8]; };   // thread (sr, sc): item rows sr and 64 + sr, columns sc*4 + 16 j (j < 4)
 
-__device__ __forceinline__ void load_slab2(const FusedArgs& p, uint32_t i0, uint32_t k0, int sr, int sc, Slab2Regs& g)
+__device__ __forceinline__ void load_tile2(const FusedArgs& p, uint32_t i0, int sr, int sc, Tile2Regs& g)
 {
     const uint32_t d = p.d, last = p.num_items - 1u;
     const float* v0 = p.V + (size_t)min(i0 + (uint32_t)sr, last) * d;
@@ -478,31 +479,29 @@ __device__ __forceinline__ void load_slab2(const FusedArgs& p, uint32_t i0, uint
 #pragma unroll
     for (int j = 0; j < 4; ++j)
     {
-        const uint32_t kk = min(k0 + (uint32_t)(sc * 4 + 16 * j), d - 4u);   // columns past emb_dim: clamped, never multiplied
+        const uint32_t kk = min((uint32_t)(sc * 4 + 16 * j), d - 4u);   // columns past emb_dim: clamped, never multiplied
         g.v[j] = *(const f4*)(v0 + kk);
         g.v[4 + j] = *(const f4*)(v1 + kk);
     }
 }
 
-template <class Shared> __device__ __forceinline__ void store_slab2(Shared& s, int buf, int sr, int sc, const Slab2Regs& g)
+__device__ __forceinline__ void store_tile2(Shared2& s, int sr, int sc, const Tile2Regs& g)
 {
 #pragma unroll
     for (int j = 0; j < 4; ++j)
     {
         const int kp = (sc * 4 + 16 * j) / 2;
-        *(f2*)&s.b[buf][kp][sr][0] = f2{g.v[j][0], g.v[j][1]};
-        *(f2*)&s.b[buf][kp + 1][sr][0] = f2{g.v[j][2], g.v[j][3]};
-        *(f2*)&s.b[buf][kp][64 + sr][0] = f2{g.v[4 + j][0], g.v[4 + j][1]};
-        *(f2*)&s.b[buf][kp + 1][64 + sr][0] = f2{g.v[4 + j][2], g.v[4 + j][3]};
+        *(f2*)&s.b[kp][sr][0] = f2{g.v[j][0], g.v[j][1]};
+        *(f2*)&s.b[kp + 1][sr][0] = f2{g.v[j][2], g.v[j][3]};
+        *(f2*)&s.b[kp][64 + sr][0] = f2{g.v[4 + j][0], g.v[4 + j][1]};
+        *(f2*)&s.b[kp + 1][64 + sr][0] = f2{g.v[4 + j][2], g.v[4 + j][3]};
     }
 }
 
-// AREG = A registers per lane = k pairs the kernel can hold (emb_dim <= 2 * AREG)
-template <int CAP, bool DBUF, int AREG> __global__ __launch_bounds__(256, DBUF ? 1 : 2) void topk_fused2_kernel(FusedArgs p)
+__global__ __launch_bounds__(256, 2) void topk_fused2_kernel(FusedArgs p)
 {
-    typedef Shared2T<CAP, DBUF> Shared;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem2[];
-    Shared& s = *reinterpret_cast<Shared*>(smem2);
+    Shared2& s = *reinterpret_cast<Shared2*>(smem2);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 31, h = lane >> 5;
     const uint32_t u0 = blockIdx.x * (uint32_t)TU2;
@@ -512,21 +511,20 @@ template <int CAP, bool DBUF, int AREG> __global__ __launch_bounds__(256, DBUF ?
     const uint32_t t_end = min(ntiles, t_begin + p.tiles_per_split);
     const uint32_t d = p.d, k = p.k;
     const uint32_t kpairs = d / 2;                              // emb_dim % 4 == 0
-    const uint32_t nslab = (d + KS2 - 1) / KS2;
 
     // A operand: lane (n, h) keeps U[ub + n][2 kp + h] for every k pair
-    float a[AREG];
+    float a[KP2];
     {
         const float* ur = p.U + (size_t)min(ub + (uint32_t)n, p.rows - 1u) * d;
 #pragma unroll
-        for (int kp = 0; kp < AREG; ++kp) a[kp] = (uint32_t)kp < kpairs ? ur[2 * kp + h] : 0.0f;
+        for (int kp = 0; kp < KP2; ++kp) a[kp] = (uint32_t)kp < kpairs ? ur[2 * kp + h] : 0.0f;
     }
     uint32_t ulive = 0u;       // bit r: the user of result register r exists
 #pragma unroll
     for (int r = 0; r < 16; ++r)
         if (ub + (uint32_t)(8 * (r >> 2) + 4 * h + (r & 3)) < p.rows) ulive |= 1u << r;
 
-    for (int t = tid; t < TU2 * CAP; t += 256)
+    for (int t = tid; t < TU2 * CAP2; t += 256)
     {
         (&s.topv[0][0])[t] = -INFINITY;
         (&s.topi[0][0])[t] = NONE;
@@ -560,25 +558,12 @@ template <int CAP, bool DBUF, int AREG> __global__ __launch_bounds__(256, DBUF ?
     }
 
     const int sr = tid >> 2, sc = tid & 3;
-    Slab2Regs regs;
+    Tile2Regs regs;
 #pragma unroll
     for (int j = 0; j < 8; ++j) regs.v[j] = f4{0, 0, 0, 0};
-    // slabs are numbered through the whole item range of this workgroup: g = (tile - t_begin) * nslab + slab
-    const uint32_t gtotal = t_begin < t_end ? (t_end - t_begin) * nslab : 0u;
-    auto slab_tile = [&](uint32_t g) { return t_begin + g / nslab; };
-    auto slab_k0 = [&](uint32_t g) { return (g % nslab) * (uint32_t)KS2; };
-    if (gtotal > 0)
-    {
-        load_slab2(p, slab_tile(0) * (uint32_t)TI, slab_k0(0), sr, sc, regs);
-        if (DBUF)
-        {
-            store_slab2(s, 0, sr, sc, regs);
-            if (gtotal > 1) load_slab2(p, slab_tile(1) * (uint32_t)TI, slab_k0(1), sr, sc, regs);
-        }
-    }
+    if (t_begin < t_end) load_tile2(p, t_begin * (uint32_t)TI, sr, sc, regs);
     __syncthreads();
 
-    uint32_t g = 0;
     for (uint32_t tile = t_begin; tile < t_end; ++tile)
     {
         const uint32_t i0 = tile * (uint32_t)TI;
@@ -597,54 +582,31 @@ template <int CAP, bool DBUF, int AREG> __global__ __launch_bounds__(256, DBUF ?
             }
         }
 
+        store_tile2(s, sr, sc, regs);                    // the tile loaded one iteration ago
+        __syncthreads();
+        if (tile + 1 < t_end) load_tile2(p, i0 + TI, sr, sc, regs);
+
         f16v acc[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[c][r] = 0.0f;
-
-        for (uint32_t sl = 0; sl < nslab; ++sl, ++g)
+        auto tile_mfma = [&](auto full_tag) __attribute__((always_inline))
         {
-            int cb = 0;
-            if (DBUF)
+#pragma unroll
+            for (int kp = 0; kp < KP2; ++kp)
             {
-                cb = (int)(g & 1u);
-                // the other buffer was last read in iteration g - 1, which every wave left through the barrier below
-                if (g + 1 < gtotal)
+                if (decltype(full_tag)::value || (uint32_t)kp < kpairs)
                 {
-                    store_slab2(s, cb ^ 1, sr, sc, regs);
-                    if (g + 2 < gtotal) load_slab2(p, slab_tile(g + 2) * (uint32_t)TI, slab_k0(g + 2), sr, sc, regs);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kp], s.b[kp][32 * c + n][h], acc[c], 0, 0, 0);
                 }
             }
-            else
-            {
-                store_slab2(s, 0, sr, sc, regs);
-                __syncthreads();
-                if (g + 1 < gtotal) load_slab2(p, slab_tile(g + 1) * (uint32_t)TI, slab_k0(g + 1), sr, sc, regs);
-            }
-            const uint32_t kbase = sl * (uint32_t)(KS2 / 2);                 // first k pair of this slab
-            // a[] is indexed statically: `sl` selects among the AREG / 32 slabs a kernel variant can see (wave-uniform)
-            auto slab_mfma = [&](auto full_tag) __attribute__((always_inline))
-            {
-#pragma unroll
-                for (int kp = 0; kp < KS2 / 2; ++kp)
-                {
-                    float av = 0.0f;
-#pragma unroll
-                    for (int q = 0; q < AREG / (KS2 / 2); ++q)
-                        if (sl == (uint32_t)q) av = a[q * (KS2 / 2) + kp];
-                    if (decltype(full_tag)::value || kbase + (uint32_t)kp < kpairs)
-                    {
-#pragma unroll
-                        for (int c = 0; c < 4; ++c)
-                            acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, s.b[cb][kp][32 * c + n][h], acc[c], 0, 0, 0);
-                    }
-                }
-            };
-            if (kbase + (uint32_t)(KS2 / 2) <= kpairs) slab_mfma(std::true_type{});
-            else slab_mfma(std::false_type{});
-            __syncthreads();
-        }
+        };
+        if (kpairs == (uint32_t)KP2) tile_mfma(std::true_type{});
+        else tile_mfma(std::false_type{});
+        __syncthreads();                                 // every wave is done with the tile in LDS
 
         // ---- selection, wave-local: lane's results acc[c][r] = user ub + 8 (r / 4) + 4 h + (r % 4), item i0 + 32 c + n
         uint32_t cand[4] = {0u, 0u, 0u, 0u};
@@ -662,7 +624,6 @@ template <int CAP, bool DBUF, int AREG> __global__ __launch_bounds__(256, DBUF ?
                 for (int c = 0; c < 4; ++c) cand[c] |= (!(acc[c][r] < t4[j]) ? 1u : 0u) << r;
             }
         }
-        if (p.ablate == 1u && acc[0][0] != 12345.678f) cand[0] = cand[1] = cand[2] = cand[3] = 0u;
 #pragma unroll
         for (int c = 0; c < 4; ++c)
         {
@@ -698,15 +659,10 @@ template <int CAP, bool DBUF, int AREG> __global__ __launch_bounds__(256, DBUF ?
                     }
                     if (done) todo &= todo - 1u;
                 }
-                if (__ballot(full) != 0ull)
-                {
-                    if (p.ablate == 2u) { if (lane == 0) s.qn[wave] = 0u; __builtin_amdgcn_wave_barrier(); }
-                    else drain2(s, k, wave, lane);                            // raises the thresholds the retries are checked against
-                }
+                if (__ballot(full) != 0ull) drain2(s, k, wave, lane);         // raises the thresholds the retries are checked against
             }
         }
-        if (p.ablate == 2u) { if (lane == 0) s.qn[wave] = 0u; __builtin_amdgcn_wave_barrier(); }
-        else if (s.qn[wave] != 0u) drain2(s, k, wave, lane);
+        if (s.qn[wave] != 0u) drain2(s, k, wave, lane);
 
         // threshold exchange between the item splits of these users (see the 64 x 128 kernel)
         if (p.thr_shared && lane < 32 && ub + lane < p.rows)
@@ -792,14 +748,6 @@ uint32_t topk_fused_splits(uint32_t rows, uint32_t num_items, uint32_t cus, uint
     const uint32_t tu = use_v2(emb_dim, k) ? (uint32_t)TU2 : (uint32_t)TU, slots = 2u * cus;   // both kernels: two workgroups per CU
     const uint32_t nblocks = (rows + tu - 1) / tu, ntiles = (num_items + TI - 1) / TI;
     if (nblocks == 0 || ntiles == 0 || slots == 0) return 1;
-    if (const char* e = std::getenv("HEAT_CF_TOPK_SPLITS"))      // experiments: force the split count (clamped to what is legal)
-    {
-        uint32_t z = (uint32_t)std::atoi(e);
-        z = z < 1 ? 1 : (z > (uint32_t)TOPK_FUSED_MAX_SPLITS ? (uint32_t)TOPK_FUSED_MAX_SPLITS : z);
-        z = z > ntiles ? ntiles : z;
-        const uint32_t per = (ntiles + z - 1) / z;
-        return (ntiles + per - 1) / per;
-    }
     uint32_t best = 1;
     double best_cost = 0.0;
     for (uint32_t z = 1; z <= (uint32_t)TOPK_FUSED_MAX_SPLITS && z <= ntiles; ++z)
@@ -813,14 +761,12 @@ uint32_t topk_fused_splits(uint32_t rows, uint32_t num_items, uint32_t cus, uint
     return best;
 }
 
-template <int CAP, bool DBUF, int AREG>
 static hipError_t launch_v2(const FusedArgs& p, uint32_t splits, hipStream_t s)
 {
-    auto kern = topk_fused2_kernel<CAP, DBUF, AREG>;
-    const size_t lds = sizeof(Shared2T<CAP, DBUF>);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const size_t lds = sizeof(Shared2);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(topk_fused2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3((p.rows + TU2 - 1) / TU2, splits), dim3(256), lds, s, p);
+    hipLaunchKernelGGL(topk_fused2_kernel, dim3((p.rows + TU2 - 1) / TU2, splits), dim3(256), lds, s, p);
     return hipGetLastError();
 }
 
@@ -838,8 +784,6 @@ hipError_t launch_topk_fused(const float* user_rows, const float* item_w, uint32
     if ((uint64_t)p.tiles_per_split * (splits - 1) >= ntiles && splits > 1) return hipErrorInvalidValue; // empty split
     p.indptr = indptr; p.items = items; p.part_v = part_v; p.part_i = part_i;
     p.thr_shared = splits > 1 ? thr_shared : nullptr;
-    p.ablate = 0u;
-    if (const char* ab = std::getenv("HEAT_CF_TOPK_ABLATE")) p.ablate = (uint32_t)std::atoi(ab);
     if (p.thr_shared)
     {
         hipError_t e0 = hipMemsetD32Async((hipDeviceptr_t)thr_shared, (int)0xFF800000u, rows, s);   // -inf
@@ -848,7 +792,7 @@ hipError_t launch_topk_fused(const float* user_rows, const float* item_w, uint32
     hipError_t err;
     if (use_v2(emb_dim, k))
     {
-        err = launch_v2<32, false, 32>(p, splits, s);
+        err = launch_v2(p, splits, s);
     }
     else
     {

@@ -591,16 +591,16 @@ def test_recall_ndcg_parity_gowalla_config():
 
 def test_accl_hogwild_parity_amazonbooks_shape():
     """Behaviour aggregation (ACCL) in Hogwild mode at AmazonBooks shape, yaml hyper-parameters, 5 epochs, the
-    engine's default plan (438 four-wave streams), three seeds per side.
+    engine's default plan (512 four-wave streams: two workgroups per compute unit), three seeds per side.
 
     Two references, because ACCL's loss curve depends on the NUMBER OF WORKERS even without any asynchrony
     (profiles/r03_accl_worker_count.txt): the 8-thread OpenMP oracle, and the oracle's own forward_backward driven as S
     lockstep workers, sequentially consistent (tests/tools/stream_sim.c; committed fixture tests/golden/accl_stream_model.json,
-    S = 8 and S = 438).  The chain that is asserted:
+    S = 8, 438 and 512).  The chain that is asserted:
       * model(8 workers)   vs the 8-thread oracle : Recall@20 +-1e-3, final loss within 5 % — the lockstep model IS the oracle;
-      * GPU (438 streams)  vs model(438 workers)  : Recall@20 +-1e-3, final loss within 3.5 % — at a matched worker count the
+      * GPU (512 streams)  vs model(512 workers)  : Recall@20 +-1e-3, final loss within 3.5 % — at a matched worker count the
         Hogwild GPU run adds nothing to what the reference's algorithm does with that many workers;
-      * GPU vs the 8-thread oracle: Recall@20 within -1e-3 ... +2e-3 (the model's own 8 -> 438 shift is +1.1e-3: more workers
+      * GPU vs the 8-thread oracle: Recall@20 within -1e-3 ... +2e-3 (the model's own 8 -> 512 shift is +1.1e-3: more workers
         rank slightly BETTER), final loss +10 ... +20 % (the model's shift: +13 %; one shared W0 pushed by S users at once).
     NDCG@20 of this mode scatters by +-4e-3 between runs of either side on the popularity-only graph, with occasional
     runs 1e-2 low (the top ranks are the hottest items, whose rows move until the last step), so it is held to 4e-3 on the
@@ -655,21 +655,21 @@ def test_accl_hogwild_parity_amazonbooks_shape():
     with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "accl_stream_model.json")) as f:
         fixture = json.load(f)
     model = {w: np.array([[r["recall20"], r["ndcg20"]] + r["losses"] for r in fixture if r["workers"] == w and r["seed"] in seeds])
-             for w in (8, 438)}
-    assert model[8].shape == model[438].shape == gpu.shape == ora.shape == (3, 7)
-    print(f"{name}\n gpu (Recall, NDCG, 5 epoch losses) per seed:\n{gpu}\n 8-thread oracle:\n{ora}\n model 8 workers:\n{model[8]}\n model 438:\n{model[438]}")
-    assert "streams=438" in name and "<16,1,16,4>" in name, name
-    g_, o_, m8, m438 = gpu.mean(axis=0), ora.mean(axis=0), model[8].mean(axis=0), model[438].mean(axis=0)
+             for w in (8, 512)}
+    assert model[8].shape == model[512].shape == gpu.shape == ora.shape == (3, 7)
+    print(f"{name}\n gpu (Recall, NDCG, 5 epoch losses) per seed:\n{gpu}\n 8-thread oracle:\n{ora}\n model 8 workers:\n{model[8]}\n model 512:\n{model[512]}")
+    assert "streams=512" in name and "<16,1,16,4>" in name, name
+    g_, o_, m8, m512 = gpu.mean(axis=0), ora.mean(axis=0), model[8].mean(axis=0), model[512].mean(axis=0)
     # the lockstep model at the oracle's worker count is the oracle
     assert abs(m8[0] - o_[0]) <= 1e-3 and abs(m8[6] - o_[6]) <= 0.05 * o_[6], (m8, o_)   # the oracle's final loss moves 1.084 ... 1.095 between boxes
     # the GPU at its worker count is the model at that worker count
-    assert abs(g_[0] - m438[0]) <= 1e-3, (g_, m438)
-    assert abs(g_[6] - m438[6]) <= 0.035 * m438[6], (g_, m438)
-    assert np.all(np.abs(g_[3:] - m438[3:]) <= 0.06 * m438[3:]), (g_, m438)          # every later epoch of the curve, loosely
+    assert abs(g_[0] - m512[0]) <= 1e-3, (g_, m512)
+    assert abs(g_[6] - m512[6]) <= 0.035 * m512[6], (g_, m512)
+    assert np.all(np.abs(g_[3:] - m512[3:]) <= 0.06 * m512[3:]), (g_, m512)          # every later epoch of the curve, loosely
     # NDCG@20: single runs of EITHER side occasionally land 1e-2 low (one of the few hottest items ends the last epoch
     # displaced: GPU seed 2022 0.2151 in one suite run, the model 0.2178 at 80 workers) — medians over the seeds, 4e-3
-    ndcg = {name_: float(np.median(a[:, 1])) for name_, a in (("gpu", gpu), ("oracle", ora), ("m438", model[438]))}
-    assert abs(ndcg["gpu"] - ndcg["m438"]) <= 4e-3 and abs(ndcg["gpu"] - ndcg["oracle"]) <= 4e-3, ndcg
+    ndcg = {name_: float(np.median(a[:, 1])) for name_, a in (("gpu", gpu), ("oracle", ora), ("m512", model[512]))}
+    assert abs(ndcg["gpu"] - ndcg["m512"]) <= 4e-3 and abs(ndcg["gpu"] - ndcg["oracle"]) <= 4e-3, ndcg
     # against the 8-thread oracle: the worker-count shift, no more
     assert -1e-3 <= g_[0] - o_[0] <= 2e-3, (g_, o_)
     assert 1.08 * o_[6] <= g_[6] <= 1.22 * o_[6], (g_, o_)
