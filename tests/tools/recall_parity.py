@@ -28,6 +28,7 @@ ap.add_argument("--lr", type=float, default=0.01)
 ap.add_argument("--zipf", type=float, default=1.0, help="item popularity exponent of the synthetic graph")
 ap.add_argument("--interactions", type=int, default=0, help="override the shape's number of train interactions")
 ap.add_argument("--in-cluster", type=float, default=0.8)
+ap.add_argument("--graph-seed", type=int, default=2022, help="seed of the synthetic graph (the tables are seeded by --seeds)")
 ap.add_argument("--users", type=int, default=0, help="with --interactions: override the shape's number of users")
 ap.add_argument("--items", type=int, default=0, help="with --interactions: override the shape's number of items")
 ap.add_argument("--oracle-seeds", type=str, default="", help="seeds the oracle runs for (default: every seed)")
@@ -39,9 +40,9 @@ args = ap.parse_args()
 if args.interactions:
     _U, _I, _T, d, N = synthetic.SHAPES[args.shape]
     _U, _I = args.users or _U, args.items or _I
-    g = synthetic.make_graph(_U, _I, args.interactions, seed=2022, n_clusters=args.clusters, zipf_s=args.zipf, in_cluster=args.in_cluster)
+    g = synthetic.make_graph(_U, _I, args.interactions, seed=args.graph_seed, n_clusters=args.clusters, zipf_s=args.zipf, in_cluster=args.in_cluster)
 else:
-    g, d, N = synthetic.make_named(args.shape, scale=args.scale, n_clusters=args.clusters, zipf_s=args.zipf, in_cluster=args.in_cluster)
+    g, d, N = synthetic.make_named(args.shape, seed=args.graph_seed, scale=args.scale, n_clusters=args.clusters, zipf_s=args.zipf, in_cluster=args.in_cluster)
 _pop = np.bincount(g.train_items, minlength=g.num_items)
 print(f"hottest item share of positives {_pop.max() / g.train_items.size:.4f}")
 test_dic = {}
