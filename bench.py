@@ -518,7 +518,7 @@ def main():
             blocking.train_one_epoch()
         fence()
         eng.kernel_time(reset=True)
-        el_b = timed(blocking.train_one_epoch, args.steps, 0, None)
+        el_b = timed(blocking.train_one_epoch, args.steps, 0, blocking.finalize if epe > 1 else None)
         kms_b, ln_b = eng.kernel_time()
         extra["item_sync_blocking"] = {"value": total_T * args.steps / el_b, "unit": "samples/s", "ms_per_step": el_b / args.steps * 1e3,
                                        "steps": args.steps, "item_sync": blocking.describe()}
