@@ -525,7 +525,11 @@ __global__ __launch_bounds__(64 * NW * TS) void ccl_train_kernel(TrainArgs a)
                     {
                         const uint32_t hh = (q0 + (uint32_t)(q * NW)) * (uint32_t)R + (uint32_t)rr;
                         const uint32_t id = his_id(hh);
+#ifdef HEATCF_EXP_NO_HIS
+                        part[q] = buf_load<AUX>(item_w, (hh < 4u && col_ok) ? id * a.row_bytes + col_off : OOB_OFF);
+#else
                         part[q] = buf_load<AUX>(item_w, (hh < agg_H && col_ok) ? id * a.row_bytes + col_off : OOB_OFF);
+#endif
                     }
 #pragma unroll
                     for (int q = 0; q < 8; ++q) hs += part[q];
@@ -923,11 +927,19 @@ __global__ __launch_bounds__(64 * NW * TS) void ccl_train_kernel(TrainArgs a)
                         const f32x4 delta = -(a.agg_lr * (acc * 0.03125f));          // :143-144 (/32 is exact as *2^-5)
                         const uint32_t off = (i < D && col_ok) ? (uint32_t)(i * D * 4) + col_off : OOB_OFF;
                         const AtomicOffsets ao = atomic_offsets(off, lane);
+#ifndef HEATCF_EXP_NO_W0_ATOMIC
                         atomic_add_tile<4>(w0_rsrc, ao, delta, tile, lane);
+#else
+                        if (delta.x == 12345.f) atomic_add_tile<4>(w0_rsrc, ao, delta, tile, lane);
+#endif
                     }
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // own W0 updates performed ...
                     if (NW > 1) __syncthreads();                                     // ... by every wave, ring free again
+#ifdef HEATCF_EXP_NO_W0_REFRESH
+                    if (w0_in_lds && agg_iter == 0xFFFFFFF0u)
+#else
                     if (w0_in_lds)
+#endif
                     {
                         for (int t = (int)threadIdx.x; t < D * D / 4; t += 64 * NW)  // ... then refresh the private copy
                             reinterpret_cast<f32x4*>(agg_w0)[t] = buf_load<AUX>(w0_rsrc, (uint32_t)t * 16u);
