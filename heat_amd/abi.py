@@ -149,8 +149,8 @@ def plan(resident_workgroups=0, data_rows=None, **cfg_kwargs):
     """The launch plan (kernel variant, streams, update policy) for a configuration, as a dict.  No GPU needed."""
     import json
     cfg = make_config(**cfg_kwargs)
-    buf = C.create_string_buffer(512)
-    _check(load().heat_cf_plan(C.byref(cfg), cfg.train_size if data_rows is None else data_rows, resident_workgroups, buf, 512))
+    buf = C.create_string_buffer(1024)
+    _check(load().heat_cf_plan(C.byref(cfg), cfg.train_size if data_rows is None else data_rows, resident_workgroups, buf, 1024))
     return json.loads(buf.value.decode())
 
 

@@ -499,80 +499,29 @@ __global__ __launch_bounds__(64 * NW * TS) void ccl_train_kernel(TrainArgs a)
                     for (int q = 0; q < 4; ++q) hid[q] = (uint32_t)(64 * q + lane) < agg_H ? hrow[64 * q + lane] : 0u;
                 }
             }
+            // ---- behaviour aggregation: the first pass of the history gather is requested before anything else, the
+            //      positive / negative rows right behind it, and the next interaction's ids are drawn in their shadow —
+            //      the aggregator's two barriers then stand behind ONE memory round trip instead of following a second
+            auto his_id = [&](uint32_t hh) {
+                uint32_t id = lane_get(hid[0], (int)(hh & 63u));
+#pragma unroll
+                for (int q = 1; q < 4; ++q)
+                {
+                    const uint32_t t = lane_get(hid[q], (int)(hh & 63u));
+                    id = (hh >> 6) == (uint32_t)q ? t : id;
+                }
+                return id;
+            };
+            f32x4 his_part[AGG ? 8 : 1];
             if (AGG)
             {
-                // ---- aggregator forward (behavior_aggregators.cpp:96-122) -----------------------------------------
-                // The H history rows are fetched R per wave instruction, instruction q by wave q % NW; the d x d product
-                // likewise by rows of W0.  With NW > 1 the per-wave partial sums cross through LDS (two barriers) and every
-                // wave adds them in the same order, so the replicated user row stays identical across waves.
-                auto his_id = [&](uint32_t hh) {
-                    uint32_t id = lane_get(hid[0], (int)(hh & 63u));
 #pragma unroll
-                    for (int q = 1; q < 4; ++q)
-                    {
-                        const uint32_t t = lane_get(hid[q], (int)(hh & 63u));
-                        id = (hh >> 6) == (uint32_t)q ? t : id;
-                    }
-                    return id;
-                };
-                f32x4 hs = {0, 0, 0, 0};
-                const uint32_t n_inst = (agg_H + (uint32_t)R - 1u) / (uint32_t)R;
-                for (uint32_t q0 = (uint32_t)wave; q0 < n_inst; q0 += (uint32_t)(NW * 8))
+                for (int q = 0; q < 8; ++q)
                 {
-                    f32x4 part[8];
-#pragma unroll
-                    for (int q = 0; q < 8; ++q)
-                    {
-                        const uint32_t hh = (q0 + (uint32_t)(q * NW)) * (uint32_t)R + (uint32_t)rr;
-                        const uint32_t id = his_id(hh);
-#ifdef HEATCF_EXP_NO_HIS
-                        part[q] = buf_load<AUX>(item_w, (hh < 4u && col_ok) ? id * a.row_bytes + col_off : OOB_OFF);
-#else
-                        part[q] = buf_load<AUX>(item_w, (hh < agg_H && col_ok) ? id * a.row_bytes + col_off : OOB_OFF);
-#endif
-                    }
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) hs += part[q];
+                    const uint32_t hh = (uint32_t)(wave + q * NW) * (uint32_t)R + (uint32_t)rr;
+                    const uint32_t id = his_id(hh);
+                    his_part[q] = buf_load<AUX>(item_w, (hh < agg_H && col_ok) ? id * a.row_bytes + col_off : OOB_OFF);
                 }
-                hs.x = cross_sum<LPR>(hs.x);
-                hs.y = cross_sum<LPR>(hs.y);
-                hs.z = cross_sum<LPR>(hs.z);
-                hs.w = cross_sum<LPR>(hs.w);
-                if (NW > 1)
-                {
-                    if (rr == 0) *reinterpret_cast<f32x4*>(agg_part_h + wave * DP + sub * 4) = hs;
-                    __syncthreads();                                                  // BA1
-                    hs = f32x4{0, 0, 0, 0};
-#pragma unroll
-                    for (int w = 0; w < NW; ++w) hs += *reinterpret_cast<const f32x4*>(agg_part_h + w * DP + sub * 4);
-                }
-                means4 = hs * (1.0f / (float)agg_H);                                  // :63,105
-                if (rr == 0) *reinterpret_cast<f32x4*>(agg_means + sub * 4) = means4;   // every wave writes the same values
-                f32x4 f4 = {0, 0, 0, 0};
-                for (int i = wave * R + rr; i < D; i += NW * R)                       // :118 f = means (1xD) * W0 (DxD)
-                {
-                    const float m = agg_means[i];
-                    f32x4 wrow = {0, 0, 0, 0};
-                    if (col_ok)
-                        wrow = w0_in_lds ? *reinterpret_cast<const f32x4*>(agg_w0 + i * D + sub * 4)
-                                         : buf_load<AUX>(w0_rsrc, (uint32_t)(i * D * 4) + col_off);
-                    f4 += m * wrow;
-                }
-                f4.x = cross_sum<LPR>(f4.x);
-                f4.y = cross_sum<LPR>(f4.y);
-                f4.z = cross_sum<LPR>(f4.z);
-                f4.w = cross_sum<LPR>(f4.w);
-                if (NW > 1)
-                {
-                    if (rr == 0) *reinterpret_cast<f32x4*>(agg_part_f + wave * DP + sub * 4) = f4;
-                    __syncthreads();                                                  // BA2
-                    f4 = f32x4{0, 0, 0, 0};
-#pragma unroll
-                    for (int w = 0; w < NW; ++w) f4 += *reinterpret_cast<const f32x4*>(agg_part_f + w * DP + sub * 4);
-                }
-                const float gamma = 0.4f, omg = 1.0f - gamma;                          // :37, :122
-                u4 = gamma * u4 + omg * f4;
-                agg_iter += 1u;                                                       // :124
             }
 
             // ---- gather: positive row (replicated in every row group) + this wave's negative rows (W only; the
@@ -621,16 +570,9 @@ __global__ __launch_bounds__(64 * NW * TS) void ccl_train_kernel(TrainArgs a)
                     if (doff[g] != 0xFFFFFFFFu) n4[g] += *reinterpret_cast<const f32x4*>(tile_delta + doff[g]);
             }
 
-            // ---- duplicate negatives inside one interaction (rare): multiplicity per slot ------------------
-            // Reference semantics (matrix_factorization.cpp:127-150): slot k re-reads G fresh, so c copies of one
-            // row apply G <- clip(G + g) c times; every copy writes W_stale - lr*G, last writer wins.  All copies
-            // compute the identical c-fold result here, so whichever store lands last is the reference's value.
-            uint32_t eq[NIDV], earlier[NIDV];
-            uint32_t cmax = 1u;
             if constexpr (NW > 1)
             {
-                // multiplicities were counted with the draw; now, while the gather is in flight, draw the NEXT interaction
-                cmax = cmax_w;
+                // while the gather is in flight, draw the NEXT interaction
                 have_next = (j + 1 < cnt) && a.ext_negs == nullptr;      // caller-fed ids (tests) are fetched at the top instead
                 if (have_next)
                 {
@@ -640,6 +582,81 @@ __global__ __launch_bounds__(64 * NW * TS) void ccl_train_kernel(TrainArgs a)
                     draw_all_ids<NIDA, false>(a, idx + 1, pos_n, first, lane, nxt_nid);
                     nxt_cmax = slot_multiplicity<NIDA, NGW, R>(nxt_nid, N, wave_base, lane, rr, nxt_mult);
                 }
+            }
+
+            if (AGG)
+            {
+                // ---- aggregator forward (behavior_aggregators.cpp:96-122) -----------------------------------------
+                // The H history rows are fetched R per wave instruction, instruction q by wave q % NW (first pass: above); the
+                // d x d product likewise by rows of W0.  With NW > 1 the per-wave partial sums cross through LDS (two barriers)
+                // and every wave adds them in the same order, so the replicated user row stays identical across waves.
+                f32x4 hs = {0, 0, 0, 0};
+                const uint32_t n_inst = (agg_H + (uint32_t)R - 1u) / (uint32_t)R;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) hs += his_part[q];
+                for (uint32_t q0 = (uint32_t)(wave + NW * 8); q0 < n_inst; q0 += (uint32_t)(NW * 8))
+                {
+                    f32x4 part[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q)
+                    {
+                        const uint32_t hh = (q0 + (uint32_t)(q * NW)) * (uint32_t)R + (uint32_t)rr;
+                        const uint32_t id = his_id(hh);
+                        part[q] = buf_load<AUX>(item_w, (hh < agg_H && col_ok) ? id * a.row_bytes + col_off : OOB_OFF);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) hs += part[q];
+                }
+                hs.x = cross_sum<LPR>(hs.x);
+                hs.y = cross_sum<LPR>(hs.y);
+                hs.z = cross_sum<LPR>(hs.z);
+                hs.w = cross_sum<LPR>(hs.w);
+                if (NW > 1)
+                {
+                    if (rr == 0) *reinterpret_cast<f32x4*>(agg_part_h + wave * DP + sub * 4) = hs;
+                    __syncthreads();                                                  // BA1
+                    hs = f32x4{0, 0, 0, 0};
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) hs += *reinterpret_cast<const f32x4*>(agg_part_h + w * DP + sub * 4);
+                }
+                means4 = hs * (1.0f / (float)agg_H);                                  // :63,105
+                if (rr == 0) *reinterpret_cast<f32x4*>(agg_means + sub * 4) = means4;   // every wave writes the same values
+                f32x4 f4 = {0, 0, 0, 0};
+                for (int i = wave * R + rr; i < D; i += NW * R)                       // :118 f = means (1xD) * W0 (DxD)
+                {
+                    const float m = agg_means[i];
+                    f32x4 wrow = {0, 0, 0, 0};
+                    if (col_ok)
+                        wrow = w0_in_lds ? *reinterpret_cast<const f32x4*>(agg_w0 + i * D + sub * 4)
+                                         : buf_load<AUX>(w0_rsrc, (uint32_t)(i * D * 4) + col_off);
+                    f4 += m * wrow;
+                }
+                f4.x = cross_sum<LPR>(f4.x);
+                f4.y = cross_sum<LPR>(f4.y);
+                f4.z = cross_sum<LPR>(f4.z);
+                f4.w = cross_sum<LPR>(f4.w);
+                if (NW > 1)
+                {
+                    if (rr == 0) *reinterpret_cast<f32x4*>(agg_part_f + wave * DP + sub * 4) = f4;
+                    __syncthreads();                                                  // BA2
+                    f4 = f32x4{0, 0, 0, 0};
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) f4 += *reinterpret_cast<const f32x4*>(agg_part_f + w * DP + sub * 4);
+                }
+                const float gamma = 0.4f, omg = 1.0f - gamma;                          // :37, :122
+                u4 = gamma * u4 + omg * f4;
+                agg_iter += 1u;                                                       // :124
+            }
+
+            // ---- duplicate negatives inside one interaction (rare): multiplicity per slot ------------------
+            // Reference semantics (matrix_factorization.cpp:127-150): slot k re-reads G fresh, so c copies of one
+            // row apply G <- clip(G + g) c times; every copy writes W_stale - lr*G, last writer wins.  All copies
+            // compute the identical c-fold result here, so whichever store lands last is the reference's value.
+            uint32_t eq[NIDV], earlier[NIDV];
+            uint32_t cmax = 1u;
+            if constexpr (NW > 1)
+            {
+                cmax = cmax_w;                                           // multiplicities were counted with the draw
 #pragma unroll
                 for (int v = 0; v < NIDV; ++v) { eq[v] = 0u; earlier[v] = 0u; }
             }
@@ -927,19 +944,11 @@ __global__ __launch_bounds__(64 * NW * TS) void ccl_train_kernel(TrainArgs a)
                         const f32x4 delta = -(a.agg_lr * (acc * 0.03125f));          // :143-144 (/32 is exact as *2^-5)
                         const uint32_t off = (i < D && col_ok) ? (uint32_t)(i * D * 4) + col_off : OOB_OFF;
                         const AtomicOffsets ao = atomic_offsets(off, lane);
-#ifndef HEATCF_EXP_NO_W0_ATOMIC
                         atomic_add_tile<4>(w0_rsrc, ao, delta, tile, lane);
-#else
-                        if (delta.x == 12345.f) atomic_add_tile<4>(w0_rsrc, ao, delta, tile, lane);
-#endif
                     }
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // own W0 updates performed ...
                     if (NW > 1) __syncthreads();                                     // ... by every wave, ring free again
-#ifdef HEATCF_EXP_NO_W0_REFRESH
-                    if (w0_in_lds && agg_iter == 0xFFFFFFF0u)
-#else
                     if (w0_in_lds)
-#endif
                     {
                         for (int t = (int)threadIdx.x; t < D * D / 4; t += 64 * NW)  // ... then refresh the private copy
                             reinterpret_cast<f32x4*>(agg_w0)[t] = buf_load<AUX>(w0_rsrc, (uint32_t)t * 16u);

@@ -138,6 +138,7 @@ struct Plan
     uint32_t update_mode = 0; // resolved HEAT_CF_UPDATE_* (or the raw 16.. form)
     uint32_t upd_bits = 0;
     const char* binding = "";  // which bound set `streams`
+    const char* regime = "";   // how the step size (l_r, clip_val) relates to what the bounds were measured at
 };
 
 // fill = workgroups the chip can keep resident for the chosen variant (from the occupancy query; 0 = unknown: caps only)
@@ -183,7 +184,18 @@ int make_plan(const heat_cf_config* cfg, uint64_t data_rows, uint64_t fill, Plan
     // the edge at 400; the same tables with 0.81 M interactions and the Gowalla shape (0.81 M) hold it at 128-170 and lose
     // 1.2e-3 - 2e-3 at 200-256; with 2 M interactions 256 holds and 400 is at the edge (+1.2e-3).  Bound: a stream walks at
     // least 5600 interactions of such an epoch (Yelp18 shape: 220 streams, Gowalla shape: 144).
-    const uint64_t min_slice = (wide && !cfg->use_aggregator) ? 5600 : 256;
+    // Every bound above was measured at the reference's yaml step size, l_r 0.01 (clip_val 1.0 with <= 17 rows, 0.1 with 65).
+    // Round 3 (profiles/r03_lr_regime.txt): AmazonBooks shape holds +-1e-3 at 3017 streams for l_r 0.03 and 0.1 as well;
+    // the Yelp18 shape at l_r 0.03 loses 2e-3 in one of two seeds at 220 streams and not at 110.  So: wide interactions walk
+    // l_r / 0.01 times more interactions per stream when l_r is larger than measured (an extrapolation, reported as such);
+    // anything beyond ten times the yaml step is reported as outside what was measured and planned the same way.
+    const double lr_ratio = (double)cfg->l_r / 0.01;
+    const bool wide_plain = wide && !cfg->use_aggregator;
+    p->regime = lr_ratio <= 1.0001 ? "measured (l_r <= 0.01)"
+                : (!wide_plain && lr_ratio <= 10.001) ? "measured (l_r <= 0.1, <= 17 rows per interaction)"
+                : (wide_plain && lr_ratio <= 3.001)  ? "extrapolated: interactions per stream scaled by l_r / 0.01 (measured at l_r 0.03: 110 streams hold, 220 do not)"
+                                                      : "outside the measured range of l_r: bounds extrapolated, validate Recall before relying on it";
+    const uint64_t min_slice = wide_plain ? (uint64_t)(5600.0 * std::max(1.0, lr_ratio)) : 256;
     p->cap_users = (uint32_t)std::min<uint64_t>(0xFFFFFFFFull, std::max<uint64_t>(1, data_rows / min_slice));
     uint64_t streams = std::min<uint64_t>(p->cap_items, p->cap_users);
     p->binding = p->cap_items <= p->cap_users ? "in-flight touches per item row" : "interactions per stream";
@@ -308,6 +320,10 @@ int common_init(heat_cf_engine* e, const heat_cf_config* cfg, uint64_t data_rows
     if (prc) return prc;
     e->auto_streams = plan.streams;
     e->upd = (int)plan.upd_bits;
+    // a stream count that rests on an asynchrony bound measured at another step size is said out loud, once per engine
+    if (std::strncmp(plan.regime, "measured", 8) != 0 && !cfg->num_streams && !(cfg->flags & HEAT_CF_FLAG_SERIAL))
+        std::fprintf(stderr, "heat_cf: note: l_r %g: %s (streams=%u, bound: %s)\n", (double)cfg->l_r, plan.regime,
+                     (unsigned)plan.streams, plan.binding);
     // with the random-tile sampler (its sampling() call) the tile lives in LDS when it fits: 12 single-wave
     // streams per workgroup share tile_size x emb_dim fp32 of accumulated weight deltas (<= 128 KB)
     e->tile_resident = tile_fits_lds(cfg, plan);
@@ -469,10 +485,10 @@ int heat_cf_plan(const heat_cf_config* cfg, uint64_t data_rows, uint64_t residen
     const int n = std::snprintf(out, (size_t)out_bytes,
                                 "{\"lanes_per_row\": %d, \"groups_per_wave\": %d, \"waves_per_workgroup\": %d, "
                                 "\"negative_capacity\": %d, \"coherence\": \"%s\", \"streams\": %u, \"cap_items\": %u, "
-                                "\"cap_users\": %u, \"binding\": \"%s\", \"update_mode\": \"%s\", \"update_bits\": %u, \"tile_in_lds\": %s}",
+                                "\"cap_users\": %u, \"binding\": \"%s\", \"regime\": \"%s\", \"update_mode\": \"%s\", \"update_bits\": %u, \"tile_in_lds\": %s}",
                                 p.lpr, p.ng, p.nw, p.ng * (64 / p.lpr) * p.nw,
                                 p.coherence == HEAT_CF_COHERENCE_DEVICE ? "device" : "plain", p.streams, p.cap_items,
-                                p.cap_users, p.binding, um, p.upd_bits, tile_fits_lds(cfg, p) ? "true" : "false");
+                                p.cap_users, p.binding, p.regime, um, p.upd_bits, tile_fits_lds(cfg, p) ? "true" : "false");
     if (n < 0 || (uint64_t)n >= out_bytes) return fail(HEAT_CF_EINVAL, "out buffer too small");
     return HEAT_CF_OK;
 }

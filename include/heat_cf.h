@@ -136,7 +136,10 @@ int         heat_cf_abi_version(void);
 const char* heat_cf_last_error(void);
 /* Launch plan the engine would use for `cfg` — kernel variant, coherence, number of streams (asynchrony cap) and update
  * policy — as a small JSON object written to `out`.  Pure host logic, no GPU needed; `resident_workgroups` is what the
- * chip keeps resident for the variant (0 = unknown: only the caps apply).  With use_aggregator != 0 an engine also
+ * chip keeps resident for the variant (0 = unknown: only the caps apply).  "binding" names the bound that set the stream
+ * count; "regime" says how l_r relates to the step size those bounds were measured at ("measured ...", "extrapolated ...",
+ * "outside the measured range ..."; an engine created outside the measured range says so once on stderr).  Give `out` at
+ * least 1024 bytes.  With use_aggregator != 0 an engine also
  * counts max_his history rows per interaction in the stream bound, which this call cannot know: read the engine's own
  * choice from heat_cf_kernel_name (".../streams=N"). */
 int         heat_cf_plan(const heat_cf_config* cfg, uint64_t data_rows, uint64_t resident_workgroups, char* out,

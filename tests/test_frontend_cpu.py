@@ -330,6 +330,15 @@ def test_launch_plan_host_logic():
     assert (y["lanes_per_row"], y["groups_per_wave"], y["waves_per_workgroup"], y["streams"]) == (32, 4, 8, 220)
     assert abi.plan(emb_dim=128, num_negs=64, num_users=29858, num_items=40981, train_size=810128)["streams"] == 144
     assert y["update_mode"] == "REREAD_POS" and y["update_bits"] == 0x1C
+    # the plan says how its bounds relate to the step size they were measured at (profiles/r03_lr_regime.txt): the yaml's
+    # l_r 0.01 everywhere, up to 0.1 with <= 17 rows per interaction; wide interactions above 0.01 walk proportionally longer
+    # slices (an extrapolation, named as such), anything further is reported as outside the measured range
+    Y = dict(emb_dim=128, num_negs=64, num_users=31668, num_items=38048, train_size=1237259)
+    assert y["regime"].startswith("measured") and p["regime"].startswith("measured")
+    assert abi.plan(l_r=0.1, **A)["regime"].startswith("measured") and abi.plan(l_r=0.1, **A)["streams"] == 3017
+    y3 = abi.plan(l_r=0.03, **Y)
+    assert y3["regime"].startswith("extrapolated") and y3["cap_users"] == 1237259 // 16800 == 73 and y3["streams"] == 73
+    assert abi.plan(l_r=0.5, **A)["regime"].startswith("outside") and abi.plan(l_r=0.1, **Y)["regime"].startswith("outside")
     # ... without device-coherent row traffic there is neither a fresh value to re-read nor an atomic: the reference's
     # literal overwrite, which stays at a worker count the reference itself could have
     yp = abi.plan(emb_dim=128, num_negs=64, num_users=31668, num_items=38048, train_size=1237259, coherence=abi.COHERENCE_PLAIN)
