@@ -35,6 +35,7 @@ constexpr uint32_t NONE = 0xFFFFFFFFu;
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 typedef float f4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u4 __attribute__((ext_vector_type(4)));
 
 constexpr int QW = 128;    // candidate queue entries per wave and tile
 
@@ -419,52 +420,77 @@ template <int CAP> __global__ __launch_bounds__(256, 2) void topk_fused_kernel(F
 //     (lane (n, h): U[32 w + n][2 kp + h], kp = 0 .. d/2: 32 registers at emb_dim 64) — no staging, no LDS reads, no barrier;
 //   * only the item tile goes through LDS (128 items x 64 k-values = 33.8 KB): two barriers per tile instead of seven, the
 //     next tile's global loads in flight under the MFMAs;
-//   * selection is wave-local: a score that passes its user's threshold goes into the WAVE'S OWN queue (LDS atomic slot
-//     counter, all lanes in parallel) and the wave then inserts its queue into its users' sorted lists, one ballot +
-//     popcount insertion per candidate against the always-current threshold.  No workgroup barrier, no cross-wave traffic;
-//   * two workgroups per compute unit (79 KB of LDS, 256 registers each): one's selection runs under the other's MFMAs.
-// AmazonBooks shape top-20: 10.6 ms against 11.9 (profiles/r03_topk_kernel_stats.csv).  Measured on the way and removed
-// (DESIGN.md section 4): one workgroup per CU with the tile double-buffered, 13.7 ms; per-user append buffers merged by rank
-// counting, 14.5; threshold exchange consumed a tile late, 15.6; filter + queueing as one static sweep over the 64
-// (column, row) pairs, 25.  At k > 32 or emb_dim > 64 the 64-user kernel stays faster and keeps those shapes.
+//   * selection is wave-local and has no queue: the scores that pass their user's threshold are one bit each in four words
+//     per lane (a compare and an add-with-carry per score); per step the first lane of EACH HALF of the wave that holds a
+//     candidate hands it over (the two halves never hold the same user) and both are inserted at once into their users'
+//     sorted lists — lane n < k owns slot n, position = popcount of its half of one ballot, one LDS round trip for both.
+//     Leader election, the register index of the score (s_set_gpr_idx), user and column of both candidates are computed
+//     on the SCALAR unit: measured per phase with s_memtime (profiles/r03_topk_timeline.txt), a step cost ~2000 cycles when
+//     its ~60 vector instructions (a 16-way select among them) waited behind the co-resident workgroup's 64-cycle MFMAs;
+//   * two workgroups per compute unit (69 KB of LDS, 256 registers each): one's selection runs under the other's MFMAs.
+// AmazonBooks shape top-20: 9.0-9.2 ms against 11.9 in round 2 (profiles/r03_topk_kernel_stats.csv; 10.1 with the per-wave
+// candidate queue this selection replaced).  Per wave and tile (25 k cycles): MFMA phase 9.4 k, insert steps 7.2 x 1.25 k,
+// waiting at the tile barrier for the slowest wave's steps 2.5 k, filter 1.2 k, tile store / mask bits / loads 1.3 k.
+// Measured on the way and removed: one workgroup per CU with the tile double-buffered, 13.7 ms;
+// per-user append buffers merged by rank counting, 14.5; threshold exchange consumed a tile late, 15.6; filter + queueing as
+// one static sweep over the 64 (column, row) pairs, 25; one step loop over all four column blocks (dynamic block index: the
+// accumulators went to scratch), 84; s_setprio around the selection, no change.  At k > 32 or emb_dim > 64 the 64-user kernel
+// stays faster and keeps those shapes.
 // Scores, order and ids are those of the kernel above (same fmaf chain per score, same (score desc, id asc) comparator).
 constexpr int TU2 = 128;          // users per workgroup
 constexpr int KP2 = 32;           // k pairs the kernel holds: emb_dim <= 64
 constexpr int CAP2 = 32;          // list slots per user: k <= 32
 constexpr int LDB2 = TI + 4;
-constexpr int QW2 = 256;          // candidate queue entries per wave
 
+struct TopEntry { float v; uint32_t i; };   // one list slot: read and written as 8 bytes
+
+// Small arrays first: everything the candidate path touches sits below 64 KB, where the LDS instructions' own 16-bit offset
+// field reaches it from one per-user base address.
 struct __attribute__((aligned(16))) Shared2
 {
-    float    b[KP2][LDB2][2];             // the item tile: [k pair][item][k parity]
-    float    topv[TU2][CAP2];             // per user: the k best so far, best first
-    uint32_t topi[TU2][CAP2];
     float    thr_v[TU2];                  // = entry k - 1, the one a candidate has to beat
     float    thr_sh[TU2];                 // best k-th score any item split of these users has published
     uint32_t thr_i[TU2];
     uint32_t mbits[TU2][4];               // train items of the current tile
-    float    qv[4][QW2];                  // per wave: candidates of the current tile, in arrival order
-    uint32_t qi[4][QW2];
-    uint8_t  qu[4][QW2];
-    uint32_t qn[4];
+    TopEntry top[TU2][CAP2];              // per user: the k best so far, best first
+    float    b[KP2][LDB2][2];             // the item tile: [k pair][item][k parity]
 };
 
-// every wave empties ITS queue into the lists of ITS users: no other wave ever touches either
-__device__ __forceinline__ void drain2(Shared2& s, uint32_t k, int wave, int lane)
+// Two candidates per step, one in each half of the wave.  Result register r of lane (n, h) belongs to user
+// 8 (r / 4) + 4 h + (r % 4): the two halves NEVER hold the same user, so half 0 can insert its candidate into its user's
+// sorted list (lane n < k owns slot n) while half 1 does the same for its own — one LDS round trip for both, each half's
+// position from its 32 bits of one ballot.
+__device__ __forceinline__ void insert_half(Shared2& s, uint32_t u, int c, int ns, uint32_t item, float v, uint32_t k, uint64_t kmask, int lane)
 {
-    const uint32_t n = min(s.qn[wave], (uint32_t)QW2);
-    for (uint32_t base = 0; base < n; base += 64)
+    // branch-free on purpose: every lane reads valid slots (CAP2 = 32 of them per user), the conditions are combined as lane
+    // masks on the scalar unit; a half without a candidate is handed v = NaN, which fails every comparison below
+    const int l = lane & 31, lm = l > 0 ? l - 1 : 0;
+    const uint32_t mb = s.mbits[u][c];
+    const float    tv = s.thr_v[u];
+    const uint32_t ti = s.thr_i[u];
+    const float    ts = s.thr_sh[u];
+    TopEntry e = s.top[u][l], pe = s.top[u][lm];
+    __asm__ volatile("" : "+v"(pe.v), "+v"(pe.i));                                  // fetched with the rest, not inside the store path
+    const bool masked = ((mb >> ns) & 1u) != 0u;                                   // a train item scores -inf (metrics.py:24)
+    v = masked ? (v == v ? -INFINITY : v) : v;
+    // one compare per ballot, combined as lane masks on the scalar unit
+    const uint64_t ahead_thr = __builtin_amdgcn_ballot_w64(v > tv) | (__builtin_amdgcn_ballot_w64(v == tv) & __builtin_amdgcn_ballot_w64(item < ti));
+    const uint64_t go = kmask & ahead_thr & __builtin_amdgcn_ballot_w64(!(v < ts)) & __builtin_amdgcn_ballot_w64(v == v);
+    const uint64_t before = go & (__builtin_amdgcn_ballot_w64(e.v > v) | (__builtin_amdgcn_ballot_w64(e.v == v) & __builtin_amdgcn_ballot_w64(e.i < item)));
+    uint32_t p0 = (uint32_t)__builtin_popcount((uint32_t)before), p1 = (uint32_t)__builtin_popcount((uint32_t)(before >> 32));
+    __asm__("" : "+s"(p0), "+s"(p1));                                              // two scalar popcounts, not a vector shift
+    const uint32_t pos = p0 ^ ((p0 ^ p1) & (lane < 32 ? 0u : 0xFFFFFFFFu));
+    if (__builtin_amdgcn_inverse_ballot_w64(go & __builtin_amdgcn_ballot_w64((uint32_t)l >= pos)))
     {
-        const uint32_t e = base + (uint32_t)lane;
-        const uint32_t cu = e < n ? (uint32_t)s.qu[wave][e] : 0u;
-        const uint32_t ci = e < n ? s.qi[wave][e] : 0u;
-        const float    cv = e < n ? s.qv[wave][e] : 0.0f;
-        const int cnt = (int)min(64u, n - base);
-        for (int j = 0; j < cnt; ++j)
-            insert(s, (uint32_t)__builtin_amdgcn_readlane((int)cu, j), (uint32_t)__builtin_amdgcn_readlane((int)ci, j),
-                   __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cv), j)), k, lane);
+        const TopEntry ne = (uint32_t)l == pos ? TopEntry{v, item} : pe;
+        s.top[u][l] = ne;
+        if ((uint32_t)l == k - 1)
+        {
+            s.thr_v[u] = ne.v;
+            s.thr_i[u] = ne.i;
+        }
     }
-    if (lane == 0) s.qn[wave] = 0u;
+    // LDS operations of one wave complete in issue order: the next step's reads see these writes
     __builtin_amdgcn_wave_barrier();
     __asm__ volatile("" ::: "memory");
 }
@@ -502,8 +528,9 @@ __global__ __launch_bounds__(256, 2) void topk_fused2_kernel(FusedArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem2[];
     Shared2& s = *reinterpret_cast<Shared2*>(smem2);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 31, h = lane >> 5;
+    const uint32_t hshift = h ? 16u : 0u, hmask = h ? 0xFFFFFFFFu : 0u;
     const uint32_t u0 = blockIdx.x * (uint32_t)TU2;
     const uint32_t ub = u0 + (uint32_t)(wave * 32);            // first user of this wave
     const uint32_t ntiles = (p.num_items + TI - 1) / TI;
@@ -524,12 +551,8 @@ __global__ __launch_bounds__(256, 2) void topk_fused2_kernel(FusedArgs p)
     for (int r = 0; r < 16; ++r)
         if (ub + (uint32_t)(8 * (r >> 2) + 4 * h + (r & 3)) < p.rows) ulive |= 1u << r;
 
-    for (int t = tid; t < TU2 * CAP2; t += 256)
-    {
-        (&s.topv[0][0])[t] = -INFINITY;
-        (&s.topi[0][0])[t] = NONE;
-    }
-    if (tid < 4) s.qn[tid] = 0u;
+    for (int t = tid; t < TU2 * CAP2; t += 256) (&s.top[0][0])[t] = TopEntry{-INFINITY, NONE};
+    const uint64_t kslots = (1ull << k) - 1ull, kmask = kslots | (kslots << 32);   // lanes whose slot (lane % 32) is below k
     if (tid < TU2)
     {
         s.thr_v[tid] = -INFINITY;
@@ -570,7 +593,7 @@ __global__ __launch_bounds__(256, 2) void topk_fused2_kernel(FusedArgs p)
         if (lane < 32)
         {
             const uint32_t u = (uint32_t)(wave * 32 + lane);
-            s.mbits[u][0] = 0; s.mbits[u][1] = 0; s.mbits[u][2] = 0; s.mbits[u][3] = 0;
+            *reinterpret_cast<u4*>(&s.mbits[u][0]) = u4{0u, 0u, 0u, 0u};
             const uint32_t tile_end = i0 + TI;
             while (nxt < tile_end)
             {
@@ -609,60 +632,56 @@ __global__ __launch_bounds__(256, 2) void topk_fused2_kernel(FusedArgs p)
         __syncthreads();                                 // every wave is done with the tile in LDS
 
         // ---- selection, wave-local: lane's results acc[c][r] = user ub + 8 (r / 4) + 4 h + (r % 4), item i0 + 32 c + n
+        // bit r of cand[c] = !(acc[c][r] < threshold of r's user), built from r = 15 down as cand = 2 cand + carry: one compare
+        // and one add-with-carry per score (vector instructions are what this phase pays for, see the insert loop below)
         uint32_t cand[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+        for (int q = 3; q >= 0; --q)
         {
             const f4 tl = *(const f4*)&s.thr_v[wave * 32 + 8 * q + 4 * h];
             const f4 ts = *(const f4*)&s.thr_sh[wave * 32 + 8 * q + 4 * h];
             const f4 t4 = f4{fmaxf(tl[0], ts[0]), fmaxf(tl[1], ts[1]), fmaxf(tl[2], ts[2]), fmaxf(tl[3], ts[3])};
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 3; j >= 0; --j)
             {
                 const int r = 4 * q + j;
 #pragma unroll
-                for (int c = 0; c < 4; ++c) cand[c] |= (!(acc[c][r] < t4[j]) ? 1u : 0u) << r;
+                for (int c = 0; c < 4; ++c)
+                    __asm__("v_cmp_nlt_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(cand[c]) : "v"(acc[c][r]), "v"(t4[j]) : "vcc");
             }
         }
 #pragma unroll
         for (int c = 0; c < 4; ++c)
         {
-            const uint32_t item = i0 + (uint32_t)(32 * c + n);
-            uint32_t todo = item < p.num_items ? (cand[c] & ulive) : 0u;
-            while (__ballot(todo != 0u) != 0ull)
+            uint32_t todo = i0 + (uint32_t)(32 * c + n) < p.num_items ? (cand[c] & ulive) : 0u;
+            uint64_t bal = __builtin_amdgcn_ballot_w64(todo != 0u);
+            while (bal != 0ull)
             {
-                bool full = false;
-                if (todo != 0u)
-                {
-                    const int r = __builtin_ctz(todo);
-                    const uint32_t u = (uint32_t)(wave * 32 + 8 * (r >> 2) + 4 * h + (r & 3));
-                    float v = 0.0f;
-#pragma unroll
-                    for (int r2 = 0; r2 < 16; ++r2)
-                        if (r2 == r) v = acc[c][r2];
-                    if ((s.mbits[u][c] >> n) & 1u) v = -INFINITY;             // a train item scores -inf (metrics.py:24)
-                    bool done = true;
-                    if (v == v && !(v < s.thr_v[u]) && !(v < s.thr_sh[u]))
-                    {
-                        const uint32_t slot = atomicAdd(&s.qn[wave], 1u);
-                        if (slot < (uint32_t)QW2)
-                        {
-                            s.qv[wave][slot] = v;
-                            s.qi[wave][slot] = item;
-                            s.qu[wave][slot] = (uint8_t)u;
-                        }
-                        else
-                        {
-                            done = false;                                     // queue full (first tiles): drain, then try again
-                            full = true;
-                        }
-                    }
-                    if (done) todo &= todo - 1u;
-                }
-                if (__ballot(full) != 0ull) drain2(s, k, wave, lane);         // raises the thresholds the retries are checked against
+                // Per step one candidate from each half of the wave is inserted (insert_half).  The first lane of a half that
+                // has a candidate is its leader; everything that can be is computed on the scalar unit from the leaders' masks.
+                uint32_t lo = (uint32_t)bal, hi = (uint32_t)(bal >> 32);
+                __asm__("" : "+s"(lo), "+s"(hi));                                  // two 32-bit scalars (not one 64-bit compare)
+                const int l0 = lo != 0u ? __builtin_ctz(lo) : 0, l1 = hi != 0u ? 32 + __builtin_ctz(hi) : 32;
+                const uint32_t t0 = (uint32_t)__builtin_amdgcn_readlane((int)todo, l0);
+                const uint32_t t1 = (uint32_t)__builtin_amdgcn_readlane((int)todo, l1);
+                const int r0 = t0 != 0u ? __builtin_ctz(t0) : 0, r1 = t1 != 0u ? __builtin_ctz(t1) : 0;
+                uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane(__float_as_int(acc[c][r0]), l0);   // uniform register index
+                uint32_t b1 = (uint32_t)__builtin_amdgcn_readlane(__float_as_int(acc[c][r1]), l1);
+                b0 = lo != 0u ? b0 : 0x7FC00000u;                                  // no candidate in this half: NaN
+                b1 = hi != 0u ? b1 : 0x7FC00000u;
+                // (user, item column) of both leaders packed into one scalar, each half shifts its own 16 bits out
+                const uint32_t u0 = (uint32_t)(wave * 32 + 8 * (r0 >> 2) + (r0 & 3));
+                const uint32_t u1 = (uint32_t)(wave * 32 + 8 * (r1 >> 2) + 4 + (r1 & 3));
+                const uint32_t pack = u0 | ((uint32_t)l0 << 8) | (u1 << 16) | ((uint32_t)(l1 - 32) << 24);
+                const uint32_t mine = pack >> hshift;
+                const uint32_t u = mine & 0xFFu;
+                const int ns = (int)((mine >> 8) & 31u);
+                const float v = __uint_as_float(b0 ^ ((b0 ^ b1) & hmask));
+                insert_half(s, u, c, ns, i0 + (uint32_t)(32 * c) + (uint32_t)ns, v, k, kmask, lane);
+                if ((lane == l0 && lo != 0u) || (lane == l1 && hi != 0u)) todo &= todo - 1u;
+                bal = __builtin_amdgcn_ballot_w64(todo != 0u);
             }
         }
-        if (s.qn[wave] != 0u) drain2(s, k, wave, lane);
 
         // threshold exchange between the item splits of these users (see the 64 x 128 kernel)
         if (p.thr_shared && lane < 32 && ub + lane < p.rows)
@@ -686,8 +705,8 @@ __global__ __launch_bounds__(256, 2) void topk_fused2_kernel(FusedArgs p)
         const uint32_t u = (uint32_t)t / k, j = (uint32_t)t % k;
         if (u0 + u >= p.rows) continue;
         const size_t o = ((size_t)blockIdx.y * p.rows + (u0 + u)) * k + j;
-        p.part_v[o] = s.topv[u][j];
-        p.part_i[o] = s.topi[u][j];
+        p.part_v[o] = s.top[u][j].v;
+        p.part_i[o] = s.top[u][j].i;
     }
 }
 
