@@ -114,10 +114,26 @@ __device__ __forceinline__ void dup_rotations(uint32_t id, bool& hit)
 // EXT = false compiles the caller-fed path (a global load) away: the draw that runs in the shadow of a gather must not
 // hand the compiler a value that MAY come from memory, or it waits for every outstanding load (vmcnt counts in order)
 // before the multiplicity count and the shadow is gone.
+// With <= 16 negatives (one id register, uniform sampler) ONE generator evaluation serves four consecutive interactions,
+// as in the single-wave variants: lane l computes slot (l & 15) of interaction idx + (l >> 4) when jj (the interaction's
+// place in its batch of 64) is a multiple of four, `raw4` keeps the result and the other three interactions only fetch
+// their 16 lanes from it.  Same (slot, interaction index) counters, hence the same ids.
 template <int NIDA, bool EXT = true>
 __device__ __forceinline__ void draw_all_ids(const TrainArgs& a, uint64_t idx, uint32_t pos, uint64_t first, int lane,
-                                             uint32_t (&nid)[NIDA])
+                                             uint32_t (&nid)[NIDA], uint32_t& raw4, int jj)
 {
+    if constexpr (NIDA == 1)
+    {
+        if (!(EXT && a.ext_negs != nullptr) && !(a.tile_size != 0u && a.sampling_call) && a.num_negs <= 16u)
+        {
+            if ((jj & 3) == 0)
+                raw4 = uniform_item(philox_draw64((uint32_t)(lane & 15), a.sample_base + idx + (uint64_t)(lane >> 4), a.key), a.num_items);
+            uint32_t id = lane_get(raw4, ((jj & 3) << 4) | (lane & 15));
+            if (!a.sampling_call && id == pos) id = nid[0];      // ignore_pos_sampling keeps the previous id
+            nid[0] = id;
+            return;
+        }
+    }
 #pragma unroll
     for (int v = 0; v < NIDA; ++v)
     {
@@ -384,6 +400,7 @@ __global__ __launch_bounds__(64 * NW * TS) void ccl_train_kernel(TrainArgs a)
     double loss_acc = 0.0;
     uint32_t raw_batch = 0u;               // raw draws of up to four interactions (BATCH4)
 
+
     for (uint64_t base = first; base < last; base += 64)
     {
         // one coalesced load brings the (user,item) pairs of the next 64 interactions (datasets/click_dataset.cpp:17-22)
@@ -439,7 +456,7 @@ __global__ __launch_bounds__(64 * NW * TS) void ccl_train_kernel(TrainArgs a)
                 }
                 else
                 {
-                    draw_all_ids<NIDA>(a, idx, pos, first, lane, nid_all);
+                    draw_all_ids<NIDA>(a, idx, pos, first, lane, nid_all, raw_batch, j);
                     cmax_w = slot_multiplicity<NIDA, NGW, R>(nid_all, N, wave_base, lane, rr, mult);
                 }
                 if (a.neg_out != nullptr && wave == 0)
@@ -502,15 +519,12 @@ __global__ __launch_bounds__(64 * NW * TS) void ccl_train_kernel(TrainArgs a)
             // ---- behaviour aggregation: the first pass of the history gather is requested before anything else, the
             //      positive / negative rows right behind it, and the next interaction's ids are drawn in their shadow —
             //      the aggregator's two barriers then stand behind ONE memory round trip instead of following a second
-            auto his_id = [&](uint32_t hh) {
-                uint32_t id = lane_get(hid[0], (int)(hh & 63u));
-#pragma unroll
-                for (int q = 1; q < 4; ++q)
-                {
-                    const uint32_t t = lane_get(hid[q], (int)(hh & 63u));
-                    id = (hh >> 6) == (uint32_t)q ? t : id;
-                }
-                return id;
+            // history slot hh = hh0 + rr with hh0 a multiple of R, the same for the whole wave: the id register (hh / 64) is
+            // wave-uniform, so ONE cross-lane fetch serves (not one per id register and a select)
+            auto his_id = [&](uint32_t hh0) {
+                const uint32_t reg = hh0 >> 6;
+                const uint32_t src = reg == 0u ? hid[0] : reg == 1u ? hid[1] : reg == 2u ? hid[2] : hid[3];
+                return lane_get(src, (int)((hh0 & 63u) + (uint32_t)rr));
             };
             f32x4 his_part[AGG ? 8 : 1];
             if (AGG)
@@ -518,8 +532,8 @@ __global__ __launch_bounds__(64 * NW * TS) void ccl_train_kernel(TrainArgs a)
 #pragma unroll
                 for (int q = 0; q < 8; ++q)
                 {
-                    const uint32_t hh = (uint32_t)(wave + q * NW) * (uint32_t)R + (uint32_t)rr;
-                    const uint32_t id = his_id(hh);
+                    const uint32_t hh0 = (uint32_t)(wave + q * NW) * (uint32_t)R, hh = hh0 + (uint32_t)rr;
+                    const uint32_t id = his_id(hh0);
                     his_part[q] = buf_load<AUX>(item_w, (hh < agg_H && col_ok) ? id * a.row_bytes + col_off : OOB_OFF);
                 }
             }
@@ -579,7 +593,7 @@ __global__ __launch_bounds__(64 * NW * TS) void ccl_train_kernel(TrainArgs a)
                     const uint32_t pos_n = (uint32_t)__builtin_amdgcn_readlane((int)pair.y, j + 1);
 #pragma unroll
                     for (int v = 0; v < NIDA; ++v) nxt_nid[v] = nid_all[v];
-                    draw_all_ids<NIDA, false>(a, idx + 1, pos_n, first, lane, nxt_nid);
+                    draw_all_ids<NIDA, false>(a, idx + 1, pos_n, first, lane, nxt_nid, raw_batch, j + 1);
                     nxt_cmax = slot_multiplicity<NIDA, NGW, R>(nxt_nid, N, wave_base, lane, rr, nxt_mult);
                 }
             }
@@ -600,8 +614,8 @@ __global__ __launch_bounds__(64 * NW * TS) void ccl_train_kernel(TrainArgs a)
 #pragma unroll
                     for (int q = 0; q < 8; ++q)
                     {
-                        const uint32_t hh = (q0 + (uint32_t)(q * NW)) * (uint32_t)R + (uint32_t)rr;
-                        const uint32_t id = his_id(hh);
+                        const uint32_t hh0 = (q0 + (uint32_t)(q * NW)) * (uint32_t)R, hh = hh0 + (uint32_t)rr;
+                        const uint32_t id = his_id(hh0);
                         part[q] = buf_load<AUX>(item_w, (hh < agg_H && col_ok) ? id * a.row_bytes + col_off : OOB_OFF);
                     }
 #pragma unroll
