@@ -118,10 +118,39 @@ __device__ __forceinline__ void dup_rotations(uint32_t id, bool& hit)
 // as in the single-wave variants: lane l computes slot (l & 15) of interaction idx + (l >> 4) when jj (the interaction's
 // place in its batch of 64) is a multiple of four, `raw4` keeps the result and the other three interactions only fetch
 // their 16 lanes from it.  Same (slot, interaction index) counters, hence the same ids.
-template <int NIDA, bool EXT = true>
-__device__ __forceinline__ void draw_all_ids(const TrainArgs& a, uint64_t idx, uint32_t pos, uint64_t first, int lane,
-                                             uint32_t (&nid)[NIDA], uint32_t& raw4, int jj)
+// With more than 16 negatives the generator call is shared ACROSS THE WAVES instead: wave w evaluates it for interaction
+// first + g NW + w of the stream's g-th group of NW interactions and leaves the raw ids in an LDS ring (two groups deep,
+// group g + 1 is drawn while group g runs; the workgroup barriers of the interactions in between order writes and reads);
+// every wave then fetches the ids of the interaction at hand from the ring — one evaluation per wave and NW interactions
+// instead of one per interaction.  The Yelp18 yaml's kernel spent a tenth of its epoch in the generator, which the shadow of
+// the gather did not cover (profiles/r03_train_timeline.txt).  Same (slot, interaction index) counters, hence the same ids.
+template <int NIDA, int NW>
+__device__ __forceinline__ void draw_group(const TrainArgs& a, uint64_t first, uint32_t g, int wave, int lane, uint32_t* ring)
 {
+    const uint64_t idx = first + (uint64_t)g * NW + (uint64_t)wave;
+    uint32_t* dst = ring + ((g & 1u) * NW + (uint32_t)wave) * (uint32_t)(NIDA * 64);
+#pragma unroll
+    for (int v = 0; v < NIDA; ++v)
+        dst[v * 64 + lane] = uniform_item(philox_draw64((uint32_t)(v * 64 + lane), a.sample_base + idx, a.key), a.num_items);
+}
+
+template <int NIDA, int NW, bool EXT = true>
+__device__ __forceinline__ void draw_all_ids(const TrainArgs& a, uint64_t idx, uint32_t pos, uint64_t first, int lane,
+                                             uint32_t (&nid)[NIDA], uint32_t& raw4, int jj, const uint32_t* ring, bool use_ring)
+{
+    if (use_ring)
+    {
+        const uint32_t k = (uint32_t)(idx - first);
+        const uint32_t* src = ring + (((k / NW) & 1u) * NW + k % NW) * (uint32_t)(NIDA * 64);
+#pragma unroll
+        for (int v = 0; v < NIDA; ++v)
+        {
+            uint32_t id = src[v * 64 + lane];
+            if (!a.sampling_call && id == pos) id = nid[v];      // ignore_pos_sampling keeps the previous id
+            nid[v] = id;
+        }
+        return;
+    }
     if constexpr (NIDA == 1)
     {
         if (!(EXT && a.ext_negs != nullptr) && !(a.tile_size != 0u && a.sampling_call) && a.num_negs <= 16u)
@@ -399,6 +428,14 @@ __global__ __launch_bounds__(64 * NW * TS) void ccl_train_kernel(TrainArgs a)
     for (int v = 0; v < NIDA; ++v) { nid_all[v] = 0u; nxt_nid[v] = 0u; }
     double loss_acc = 0.0;
     uint32_t raw_batch = 0u;               // raw draws of up to four interactions (BATCH4)
+    // multi-wave variants with more than 16 negatives share the generator through an LDS ring (draw_group)
+    __shared__ uint32_t id_ring[NW > 1 ? 2 * NW * NIDA * 64 : 1];
+    const bool use_ring = NW > 1 && a.ext_negs == nullptr && !(a.tile_size != 0u && a.sampling_call) && a.num_negs > 16u;
+    if (NW > 1 && use_ring)
+    {
+        draw_group<NIDA, NW>(a, first, 0u, wave, lane, id_ring);
+        __syncthreads();
+    }
 
 
     for (uint64_t base = first; base < last; base += 64)
@@ -456,7 +493,7 @@ __global__ __launch_bounds__(64 * NW * TS) void ccl_train_kernel(TrainArgs a)
                 }
                 else
                 {
-                    draw_all_ids<NIDA>(a, idx, pos, first, lane, nid_all, raw_batch, j);
+                    draw_all_ids<NIDA, NW>(a, idx, pos, first, lane, nid_all, raw_batch, j, id_ring, use_ring);
                     cmax_w = slot_multiplicity<NIDA, NGW, R>(nid_all, N, wave_base, lane, rr, mult);
                 }
                 if (a.neg_out != nullptr && wave == 0)
@@ -593,9 +630,13 @@ __global__ __launch_bounds__(64 * NW * TS) void ccl_train_kernel(TrainArgs a)
                     const uint32_t pos_n = (uint32_t)__builtin_amdgcn_readlane((int)pair.y, j + 1);
 #pragma unroll
                     for (int v = 0; v < NIDA; ++v) nxt_nid[v] = nid_all[v];
-                    draw_all_ids<NIDA, false>(a, idx + 1, pos_n, first, lane, nxt_nid, raw_batch, j + 1);
+                    draw_all_ids<NIDA, NW, false>(a, idx + 1, pos_n, first, lane, nxt_nid, raw_batch, j + 1, id_ring, use_ring);
                     nxt_cmax = slot_multiplicity<NIDA, NGW, R>(nxt_nid, N, wave_base, lane, rr, nxt_mult);
                 }
+                // the first interaction of a group of NW draws the next group (this wave: its w-th interaction) into the other
+                // half of the ring: last read two interactions ago, first read NW - 1 interactions from now
+                if (use_ring && (uint32_t)(idx - first) % (uint32_t)NW == 0u)
+                    draw_group<NIDA, NW>(a, first, (uint32_t)(idx - first) / (uint32_t)NW + 1u, wave, lane, id_ring);
             }
 
             if (AGG)
