@@ -1,9 +1,11 @@
 set -u
 cd /root/repo; mkdir -p gpurun_out/r03 && export TMPDIR=/tmp
-o=gpurun_out/r03/wide_ring_ablate.txt
+o=gpurun_out/r03/pipeline.txt
 : > $o
-for lib in libheat_cf.so exp/libheat_cf_nomult.so exp/libheat_cf_hash.so exp/libheat_cf_both.so; do
-  echo "## lib=$lib" >> $o
-  HEAT_CF_LIB=$PWD/heat_amd/lib/$lib timeout -k 10 200 python tools/quick_bench.py --shape yelp18 --epochs 4 --streams 0 >> $o 2>&1 || exit 1
+for np in 1 ""; do
+  echo "## HEAT_CF_NO_PIPELINE=$np" >> $o
+  env ${np:+HEAT_CF_NO_PIPELINE=1} timeout -k 10 200 python tools/quick_bench.py --shape amazonbooks --epochs 5 --streams 0,1024,3017 >> $o 2>&1 || exit 1
+  env ${np:+HEAT_CF_NO_PIPELINE=1} timeout -k 10 200 python tools/quick_bench.py --shape gowalla_pr1 --epochs 5 --streams 0 >> $o 2>&1 || exit 1
+  env ${np:+HEAT_CF_NO_PIPELINE=1} timeout -k 10 200 python tools/shard_bench.py --world 8 --epochs 20 >> $o 2>&1 || exit 1
 done
-grep "^##\|coherence" $o | cut -c1-150
+grep "^##\|coherence\|epoch-shard" $o | cut -c1-170
