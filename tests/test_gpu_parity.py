@@ -869,12 +869,14 @@ def _topk_want(sim, indptr, items, k):
     (100, 5000, 128, 1, "random"),
     (65, 700, 20, 7, "random"),         # emb_dim not a multiple of the 16-wide k slab
     (3, 30, 4, 20, "mostly_masked"),    # fewer than k unmasked items: -inf entries fill the list in id order
-    (130, 3000, 64, 20, "ascending"),   # every tile beats the thresholds: queue overflow rounds on every tile
+    (130, 3000, 64, 20, "ascending"),   # every tile beats the thresholds: every score of every tile is a candidate
     (64, 900, 64, 20, "ties"),          # repeated item rows: equal scores rank by item id
     (1, 129, 8, 5, "random"),
     (300, 2000, 256, 33, "random"),     # 128-user workgroups: 4 item slabs per tile, 64-slot lists, single-buffered slab
     (257, 1500, 96, 32, "random"),      # a slab that ends inside emb_dim, k at the 32-slot list capacity, one user in the last block
-    (129, 4000, 64, 20, "ascending_users"),  # scores ascending in item id: every buffer overflows inside a tile
+    (129, 4000, 64, 20, "ascending_users"),  # scores ascending in item id: every score is inserted, in both halves of a wave
+    (200, 2500, 64, 32, "random"),      # 128-user kernel at its list capacity (all 32 lanes of a half hold a slot)
+    (90, 1000, 32, 1, "random"),        # ... and at k = 1 (slot 0 is the threshold)
 ])
 def test_topk_fused_matches_numpy_and_panel_path(U, I, d, k, case, monkeypatch):
     """the fused U*V^T + mask + top-k (no score matrix) returns exactly the ids numpy's stable
