@@ -465,7 +465,7 @@ def main():
         traffic, traffic_src = (None, None)
         if world == 1 and args.shape in ("amazonbooks", "yelp18") and args.update_mode == 0 and args.num_streams == 0:
             traffic, traffic_src = replayed_traffic("r03_pmc_traffic.json" if args.shape == "amazonbooks" else
-                                                    "r02_pmc_traffic_yelp18.json", eng.kernel_name)
+                                                    "r03_pmc_traffic_yelp18.json", eng.kernel_name)
         out = {
             "metric": "positive-samples/sec/node (AmazonBooks d=64, negs=16)" if args.shape == "amazonbooks"
             else f"positive-samples/sec/node ({args.shape} d={d}, negs={N})",

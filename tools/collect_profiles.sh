@@ -14,6 +14,8 @@ cp $(newest "$o/pmc_fetch_hbm/*/*_counter_collection.csv") $p/${r}_pmc_fetch_hbm
 cp $(newest "$o/pmc_write_hbm/*/*_counter_collection.csv") $p/${r}_pmc_write_hbm_counter_collection.csv
 cp $o/bench_yelp18.json $p/${r}_bench_yelp18.json
 cp $(newest "$o/prof_yelp18/*/*_kernel_stats.csv") $p/${r}_bench_yelp18_kernel_stats.csv
+cp $(newest "$o/pmc_fetch_yelp18/*/*_counter_collection.csv") $p/${r}_pmc_fetch_yelp18_counter_collection.csv
+cp $(newest "$o/pmc_write_yelp18/*/*_counter_collection.csv") $p/${r}_pmc_write_yelp18_counter_collection.csv
 cp $o/bench_gowalla.json $p/${r}_bench_gowalla.json
 cp $o/bench_gowalla_pr1.json $p/${r}_bench_gowalla_pr1.json
 cp $o/bench_forcesync.json $p/${r}_bench_forcesync.json
@@ -25,10 +27,10 @@ cp $o/accl_under_rocprof.txt $p/${r}_accl_quick_bench.txt
 cp $o/shard_bench_exchange_modes.txt $p/${r}_shard_bench_exchange_modes.txt
 python - <<PY
 import json, subprocess, sys
-for tag, bench in (("", "$o/bench_n1.json"), ("_hbm", "$o/bench_hbm_under_rocprof.json")):
+for tag, bench in (("", "$o/bench_n1.json"), ("_hbm", "$o/bench_hbm_under_rocprof.json"), ("_yelp18", "$o/bench_yelp18.json")):
     d = json.load(open(bench))
-    rf = d["roofline"] if tag == "" else d.get("roofline_hbm_resident", d["roofline"])
-    kernel = (d["config"]["kernel"] if tag == "" else rf.get("kernel", d["config"]["kernel"]))
+    rf = d.get("roofline_hbm_resident", d["roofline"]) if tag == "_hbm" else d["roofline"]
+    kernel = rf.get("kernel", d["config"]["kernel"]) if tag == "_hbm" else d["config"]["kernel"]
     inter = round(rf["algorithmic_gb_per_launch"] * 1e9 / rf["bytes_per_interaction"])
     subprocess.check_call([sys.executable, "tools/pmc_traffic.py", "$p/${r}_pmc_fetch%s_counter_collection.csv" % tag,
                            "$p/${r}_pmc_write%s_counter_collection.csv" % tag, "$p/${r}_pmc_traffic%s.json" % tag, kernel,

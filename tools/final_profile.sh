@@ -12,6 +12,9 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $o/pro
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $o/pmc_fetch_hbm -- python3 bench.py $H > $o/pmc_fetch_hbm.json 2> $o/pmc_fetch_hbm.err; echo "fetch hbm rc=$?"
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $o/pmc_write_hbm -- python3 bench.py $H > $o/pmc_write_hbm.json 2> $o/pmc_write_hbm.err; echo "write hbm rc=$?"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $o/prof_yelp18 -- python3 bench.py --shape yelp18 --steps 10 --warmup 2 --no-cpu-baseline --no-extra-legs > $o/bench_yelp18.json 2> $o/prof_yelp18.err; echo "prof yelp rc=$?"
+Y="--shape yelp18 --steps 3 --warmup 1 --no-cpu-baseline --no-extra-legs"
+timeout -k 10 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $o/pmc_fetch_yelp18 -- python3 bench.py $Y > $o/pmc_fetch_yelp18.json 2> $o/pmc_fetch_yelp18.err; echo "fetch yelp rc=$?"
+timeout -k 10 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $o/pmc_write_yelp18 -- python3 bench.py $Y > $o/pmc_write_yelp18.json 2> $o/pmc_write_yelp18.err; echo "write yelp rc=$?"
 for s in gowalla gowalla_pr1; do timeout -k 10 200 python bench.py --shape $s --steps 5 --warmup 1 --no-cpu-baseline --no-extra-legs > $o/bench_$s.json 2>> $o/bench.err; done
 HEAT_BENCH_FORCE_SYNC=1 timeout -k 10 200 python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extra-legs > $o/bench_forcesync.json 2>> $o/bench.err
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $o/prof_topk -- python3 tools/eval_bench.py amazonbooks 20,50 fused > $o/topk_under_rocprof.txt 2> $o/prof_topk.err; echo "topk rc=$?"
