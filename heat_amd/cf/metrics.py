@@ -77,7 +77,23 @@ def _score_per_user(top_k_items, true_items, callers):
     return np.array([[fn([int(x) for x in top], true, k) for fn, k in callers] for top, true in zip(top_k_items, true_items)])
 
 
-def _score_vectorised(top_k_items, true_items, callers):
+def _flatten_true(true_items, n, cache):
+    """(lengths, concatenated ids) of the first n test lists.  The lists are Python lists of a dict that does not change between
+    the evaluations of a run (cf/main.py evaluates the same test set every eval_interval epochs), and walking 500 k ints
+    through the interpreter is most of an evaluation's host time — so the arrays are kept in `cache` (a dict the caller
+    hangs on its test-data object) under a fingerprint of the lists: count, total length, first and last id of every 64th."""
+    probe = true_items[:n:64]
+    key = (n, tuple((len(t), t[0] if len(t) else -1, t[-1] if len(t) else -1) for t in probe))
+    if cache is not None and cache.get("key") == key and cache.get("total") == sum(len(t) for t in true_items[:n]):
+        return cache["n_true"], cache["flat_true"]
+    n_true = np.fromiter((len(t) for t in true_items[:n]), dtype=np.int64, count=n)
+    flat_true = np.fromiter((int(x) for t in true_items[:n] for x in t), dtype=np.int64, count=int(n_true.sum()))
+    if cache is not None:
+        cache.update(key=key, total=int(n_true.sum()), n_true=n_true, flat_true=flat_true)
+    return n_true, flat_true
+
+
+def _score_vectorised(top_k_items, true_items, callers, cache=None):
     """Same per-user values, bit for bit, from a [users, k] hit matrix: membership by one sorted-key lookup, every sum over
     the rank positions accumulated position by position in the loop order of the functions above (adding 0.0 for a miss
     is exact), so the averages equal the per-user loop's.  Needs distinct ids per top-k row (a top-k list has them; _score
@@ -85,8 +101,7 @@ def _score_vectorised(top_k_items, true_items, callers):
     n = min(len(top_k_items), len(true_items))
     kmax = max(k for _, k in callers)
     top = np.asarray(top_k_items)[:n, :kmax].astype(np.int64)
-    n_true = np.fromiter((len(t) for t in true_items[:n]), dtype=np.int64, count=n)
-    flat_true = np.fromiter((int(x) for t in true_items[:n] for x in t), dtype=np.int64, count=int(n_true.sum()))
+    n_true, flat_true = _flatten_true(true_items, n, cache)
     span = int(max(top.max(initial=0), flat_true.max(initial=0))) + 1
     row_of_true = np.repeat(np.arange(n, dtype=np.int64), n_true)
     keys = np.unique(row_of_true * span + flat_true)
@@ -132,7 +147,7 @@ def _score_vectorised(top_k_items, true_items, callers):
     return out
 
 
-def _score(top_k_items, test_items_dic, test_user_ids, metrics, quiet=False):
+def _score(top_k_items, test_items_dic, test_user_ids, metrics, quiet=False, cache=None):
     callers = [_parse(m) for m in metrics]
     true_items = [test_items_dic[u] for u in test_user_ids]
     # metrics.py:31-32 zips ROW i of the top-k matrix with the i-th test user (not with row `user id`)
@@ -141,7 +156,7 @@ def _score(top_k_items, test_items_dic, test_user_ids, metrics, quiet=False):
     if rows.ndim != 2 or rows.shape[0] == 0 or (srt[:, 1:] == srt[:, :-1]).any():    # repeated ids in a row: set semantics
         results = _score_per_user(top_k_items, true_items, callers)
     else:
-        results = _score_vectorised(rows, true_items, callers)
+        results = _score_vectorised(rows, true_items, callers, cache)
     average_result = np.average(results, axis=0).tolist()
     if not quiet:
         print('[Metrics] ' + ' - '.join('{}: {:.6f}'.format(k, v) for k, v in zip(metrics, average_result)))
@@ -162,7 +177,15 @@ def evaluate_metrics(train_data, test_data, sim_matrix, metrics, quiet=False):
     part = sim_matrix[np.arange(item_indices.shape[0])[:, None], item_indices]
     sorted_ids = np.argsort(-part, axis=1)                                                      # :28
     top_k_items = item_indices[np.arange(sorted_ids.shape[0])[:, None], sorted_ids]
-    return _score(top_k_items, test_items_dic, test_user_ids, metrics, quiet)
+    return _score(top_k_items, test_items_dic, test_user_ids, metrics, quiet, _cache_of(test_data))
+
+
+def _cache_of(test_data):
+    """a dict on the test-data object for _flatten_true (None for objects that cannot carry one)"""
+    try:
+        return test_data.__dict__.setdefault("_heat_metrics_cache", {})
+    except AttributeError:
+        return None
 
 
 def evaluate_topk(test_data, top_k_items, metrics, quiet=False, by_user_id=False):
@@ -173,4 +196,4 @@ def evaluate_topk(test_data, top_k_items, metrics, quiet=False, by_user_id=False
     if max(_parse(m)[1] for m in metrics) > top_k_items.shape[1]:
         raise ValueError("top_k_items holds fewer columns than the largest k requested")
     rows = top_k_items[np.asarray(test_user_ids, dtype=np.int64)] if by_user_id else top_k_items
-    return _score(rows, test_items_dic, test_user_ids, metrics, quiet)
+    return _score(rows, test_items_dic, test_user_ids, metrics, quiet, _cache_of(test_data))

@@ -388,3 +388,24 @@ def test_ingest_cache_roundtrip(tmp_path):
         path.write_text(path.read_text() + "4 1 2\n")            # the source changed: the cache must not be used
         c = ClickDataset(str(path), config=CFConfig(emb_dim=64, num_negs=4, max_his=4, milestones=[10]), seed=1)
     assert c.click_dataset.shape[0] == a.click_dataset.shape[0] + 2 and c.user_items_dic[4] == [1, 2]
+
+
+def test_metrics_cache_follows_the_test_lists():
+    """evaluate_topk keeps the flattened test lists on the test-data object between evaluations (cf/main.py scores the same
+    test set every eval_interval epochs); a changed list must be noticed, and the cached path must give the same numbers."""
+    import types
+    rng = np.random.default_rng(3)
+    U, I, k = 300, 500, 20
+    dic = {u: rng.choice(I, size=int(rng.integers(1, 30)), replace=False).tolist() for u in range(U)}
+    test = types.SimpleNamespace(user_items_dic=dic)
+    top = np.argsort(rng.random((U, I)), axis=1)[:, :k].astype(np.uint32)
+    ms = ["Recall(k=20)", "NDCG(k=20)", "HitRate(k=10)"]
+    first = M.evaluate_topk(test, top, ms, quiet=True, by_user_id=True)
+    assert "_heat_metrics_cache" in test.__dict__
+    assert M.evaluate_topk(test, top, ms, quiet=True, by_user_id=True) == first          # served from the cache
+    fresh = types.SimpleNamespace(user_items_dic={u: list(v) for u, v in dic.items()})
+    assert M.evaluate_topk(fresh, top, ms, quiet=True, by_user_id=True) == first
+    dic[7] = dic[7] + [int(top[7, 0])] if int(top[7, 0]) not in dic[7] else dic[7][:-1]   # one list changes length
+    changed = M.evaluate_topk(test, top, ms, quiet=True, by_user_id=True)
+    want = M.evaluate_topk(types.SimpleNamespace(user_items_dic={u: list(v) for u, v in dic.items()}), top, ms, quiet=True, by_user_id=True)
+    assert changed == want and changed != first
