@@ -106,7 +106,7 @@ __device__ __forceinline__ void dup_rotations(uint32_t id, bool& hit)
     dup_rot_step<13>(id, hit); dup_rot_step<14>(id, hit); dup_rot_step<15>(id, hit);
 }
 
-// ---- multi-wave workgroups (NW > 1): every wave draws ALL negative slots of the interaction itself ---------------------
+// ---- multi-wave workgroups (NW > 1): every wave HOLDS all negative slots of the interaction (who evaluates the generator: below) --
 // Lane k, register v holds slot v*64 + k.  The ~100-instruction generator is cheaper than sharing ids through LDS: no
 // barrier, and every wave can count the multiplicity of ITS slots against all ids with one compare + ballot per slot
 // instead of a num_negs-iteration scan.  The draws do not depend on table data, so the kernel evaluates them for the
@@ -290,7 +290,9 @@ __device__ __forceinline__ void flush_user_row(const TrainArgs& a, uint32_t user
 // [w*NGW*R, (w+1)*NGW*R); user and positive rows are replicated in every wave's registers (every wave computes the
 // identical update of them, wave 0 writes them back).  Softmax statistics and the user-gradient partial sums cross
 // waves through LDS (two workgroup barriers per interaction: softmax statistics, user-gradient partials); every wave
-// draws all negative ids itself (no id exchange).  NW = 1 compiles all of that away.
+// holds all negative ids of the interaction (no exchange of the ids the dots need; since round 3 the GENERATOR CALL is shared:
+// one evaluation per four interactions with <= 16 negatives, one per wave and NW interactions through an LDS ring otherwise,
+// draw_group).  NW = 1 compiles all of that away.
 //
 // AGG = true adds the reference's behaviour aggregation (behavior_aggregators/behavior_aggregators.cpp:51-153, called
 // unconditionally at matrix_factorization.cpp:38,152): u <- 0.4 u + 0.6 (mean of the user's history item rows) W0, in
