@@ -440,7 +440,7 @@ template <int CAP> __global__ __launch_bounds__(256, 2) void topk_fused_kernel(F
 constexpr int TU2 = 128;          // users per workgroup
 constexpr int KP2 = 32;           // k pairs the kernel holds: emb_dim <= 64
 constexpr int CAP2 = 32;          // list slots per user: k <= 32
-constexpr int LDB2 = TI + 4;
+constexpr int LDB2 = TI + 2;      // 130: the store's four k-pair groups of a half-wave land 8 banks apart (2 * 2 * 130 mod 32)
 
 struct TopEntry { float v; uint32_t i; };   // one list slot: read and written as 8 bytes
 
@@ -453,7 +453,9 @@ struct __attribute__((aligned(16))) Shared2
     uint32_t thr_i[TU2];
     uint32_t mbits[TU2][4];               // train items of the current tile
     TopEntry top[TU2][CAP2];              // per user: the k best so far, best first
-    float    b[KP2][LDB2][2];             // the item tile: [k pair][item][k parity]
+    float    b[KP2][2][LDB2];             // the item tile: [k pair][k parity][item] — the 32 lanes of an MFMA half read 32
+                                          // consecutive floats (32 LDS banks: [item][parity] made every read a 2-way conflict,
+                                          // 39 % of the LDS cycles by SQ_LDS_BANK_CONFLICT)
 };
 
 // Two candidates per step, one in each half of the wave.  Result register r of lane (n, h) belongs to user
@@ -517,10 +519,10 @@ __device__ __forceinline__ void store_tile2(Shared2& s, int sr, int sc, const Ti
     for (int j = 0; j < 4; ++j)
     {
         const int kp = (sc * 4 + 16 * j) / 2;
-        *(f2*)&s.b[kp][sr][0] = f2{g.v[j][0], g.v[j][1]};
-        *(f2*)&s.b[kp + 1][sr][0] = f2{g.v[j][2], g.v[j][3]};
-        *(f2*)&s.b[kp][64 + sr][0] = f2{g.v[4 + j][0], g.v[4 + j][1]};
-        *(f2*)&s.b[kp + 1][64 + sr][0] = f2{g.v[4 + j][2], g.v[4 + j][3]};
+        s.b[kp][0][sr] = g.v[j][0];          s.b[kp][1][sr] = g.v[j][1];
+        s.b[kp + 1][0][sr] = g.v[j][2];      s.b[kp + 1][1][sr] = g.v[j][3];
+        s.b[kp][0][64 + sr] = g.v[4 + j][0]; s.b[kp][1][64 + sr] = g.v[4 + j][1];
+        s.b[kp + 1][0][64 + sr] = g.v[4 + j][2]; s.b[kp + 1][1][64 + sr] = g.v[4 + j][3];
     }
 }
 
@@ -623,7 +625,7 @@ __global__ __launch_bounds__(256, 2) void topk_fused2_kernel(FusedArgs p)
                 {
 #pragma unroll
                     for (int c = 0; c < 4; ++c)
-                        acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kp], s.b[kp][32 * c + n][h], acc[c], 0, 0, 0);
+                        acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kp], s.b[kp][h][32 * c + n], acc[c], 0, 0, 0);
                 }
             }
         };
