@@ -370,7 +370,7 @@ class ShardedTrainer:
     def __init__(self, clicks, user_w, item_w, *, num_negs, rank=None, world_size=None, device=None, seed=2022,
                  refresh_interval=8192, sync_interactions=0, mode="sum", engine_factory=None, balance="users",
                  his=None, masks=None, w0=None, negatives=None, overlap=False, defer_final=False, windows_per_epoch=0,
-                 collective="all_reduce", **cfg_kwargs):
+                 collective="all_reduce", epochs_per_exchange=1, **cfg_kwargs):
         import torch
         import torch.distributed as dist
         self.torch = torch
@@ -431,7 +431,8 @@ class ShardedTrainer:
                              mean_tensors=(self.t_w0,) if self.aggregate else (), overlap=overlap, defer_final=defer_final,
                              windows_per_epoch=windows_per_epoch,
                              negatives=None if negatives is None else
-                             np.ascontiguousarray(negatives[base:base + self.shard.shape[0]], dtype=np.uint64), collective=collective)
+                             np.ascontiguousarray(negatives[base:base + self.shard.shape[0]], dtype=np.uint64), collective=collective,
+                             epochs_per_exchange=epochs_per_exchange)
 
     def train_one_epoch(self, want_loss=False):
         """One epoch on this rank's shard.  want_loss=True returns the GLOBAL mean loss (loss sums and interaction counts

@@ -38,6 +38,7 @@ def main():
     overlap = len(sys.argv) > 4 and sys.argv[4] in ("overlap", "defer")
     defer = len(sys.argv) > 4 and sys.argv[4] == "defer"      # bench.py's steady state: the closing exchange of an epoch overlaps too
     collective = sys.argv[5] if len(sys.argv) > 5 else "all_reduce"
+    every = int(sys.argv[6]) if len(sys.argv) > 6 else 1      # epochs between exchanges (bench.py at 8 GPUs: 2)
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     data = np.load(os.path.join(out_dir, "problem.npz"))
@@ -51,7 +52,7 @@ def main():
 
     agg = dict(his=data["his"], masks=data["masks"], w0=data["w0"]) if "w0" in data.files else {}
     tr = ShardedTrainer(clicks, data["uw"], data["iw"], num_negs=N, sync_interactions=window, mode=mode,
-                        engine_factory=oracle_factory, overlap=overlap, defer_final=defer, collective=collective, **agg)
+                        engine_factory=oracle_factory, overlap=overlap, defer_final=defer, collective=collective, epochs_per_exchange=every, **agg)
     for _ in range(int(data["epochs"])):
         tr.train_one_epoch()
     tr.sync.finalize()

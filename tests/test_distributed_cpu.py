@@ -258,3 +258,24 @@ def test_deferred_closing_exchange_drains_to_identical_replicas(tmp_path):
         ref.epoch = ref.epoch + 1
     np.testing.assert_allclose(ranks[0]["iw"], i1, rtol=0, atol=2e-5)
     np.testing.assert_allclose(np.concatenate([ranks[0]["uw"], ranks[1]["uw"]]), u1, rtol=0, atol=2e-5)
+
+
+@pytest.mark.timeout(400)
+@pytest.mark.parametrize("schedule", ["blocking", "defer"])
+def test_exchange_every_second_epoch_loses_nothing(tmp_path, schedule):
+    """bench.py's schedule at 8 GPUs (ItemSync(epochs_per_exchange=2)): whole epochs between exchanges, finalize() closes.
+    Every rank takes the same decision at every boundary (two exchanges for four epochs), the replicas end bit-identical,
+    and with shards that touch disjoint item rows the result is single-process training of the whole list."""
+    clicks, negs, uw, iw, U, N = make_problem(tmp_path, disjoint_items=True, epochs=4)
+    ranks = run_world(tmp_path, "sum", window=0, extra=[schedule, "all_reduce", "2"])
+    assert np.array_equal(ranks[0]["iw"], ranks[1]["iw"])
+    assert int(ranks[0]["exchanges"]) == int(ranks[1]["exchanges"]) <= 3          # epochs 2 and 4 (+ the closing one of finalize)
+    u1, i1 = uw.copy(), iw.copy()
+    ref = orc.Engine(clicks, u1, i1, num_negs=N, l_r=0.01, clip_val=1.0)
+    for _ in range(4):
+        ref.lr_step()
+        ref.train_range(0, clicks.shape[0], negs)
+        ref.zero_grad()
+        ref.epoch = ref.epoch + 1
+    np.testing.assert_allclose(ranks[0]["iw"], i1, rtol=0, atol=2e-5)
+    np.testing.assert_allclose(np.concatenate([ranks[0]["uw"], ranks[1]["uw"]]), u1, rtol=0, atol=2e-5)
